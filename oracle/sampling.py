@@ -1,0 +1,255 @@
+"""Sampling loops, data normalisation and metrics (oracle; test infrastructure only).
+
+In-repo diffusion maths: transformer4planning/models/diffusion_loss/TrajRefiner.py
+  :238-313 (x0 / eps conversions, posterior, p_sample), :315-333 (p_sample_loop),
+  :335-376 (ddim_sample), :378-386 (sample + residual);
+decoder twin: transformer4planning/models/diffusion_loss/diffusion_decoder.py:377-479;
+normalisation: transformer4planning/models/utils.py:56-80;
+chunk loop: transformer4planning/models/backbone/DiffusionAugmentation.py:137-195;
+flattened-chunk wrapper: transformer4planning/models/backbone/ExplicitDiT.py:139-210 with
+  transformer4planning/models/diffusion_loss/traj_diffusion.py:45-81;
+metrics: transformer4planning/trainer.py:184-234.
+
+Noise is always host-supplied: ``noise[0]`` initialises x_N, ``noise[1+i]`` is the
+i-th tensor the loop draws (see tests/golden/make_golden.py for the order).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import schedules
+
+
+# ------------------------------------------------------------------ data normalisation
+def normalize(x: torch.Tensor) -> torch.Tensor:
+    """utils.py:56-70: x/25-1, y/5, remaining channels copied."""
+    y = x.clone()
+    y[..., 0] = x[..., 0] / 25 - 1.0
+    y[..., 1] = x[..., 1] / 5
+    return y
+
+
+def denormalize(y: torch.Tensor) -> torch.Tensor:
+    """utils.py:72-80: (x+1)*25, y*5, channel 2 forced to 0, channel 3 copied."""
+    x = y.clone()
+    x[..., 0] = (y[..., 0] + 1.0) * 25
+    x[..., 1] = y[..., 1] * 5
+    if y.shape[-1] > 2:
+        x[..., 2] = 0
+    return x
+
+
+def _buf(b: Dict[str, np.ndarray], key: str, t: int) -> torch.Tensor:
+    return torch.tensor(b[key][t], dtype=torch.float32)
+
+
+# ------------------------------------------------------------------ in-repo DDPM / DDIM
+def x0_from_output(b, objective: str, x, out, t: int):
+    if objective == "pred_noise":
+        return _buf(b, "sqrt_recip_alphas_cumprod", t) * x - _buf(b, "sqrt_recipm1_alphas_cumprod", t) * out
+    if objective == "pred_x0":
+        return out
+    if objective == "pred_v":
+        return _buf(b, "sqrt_alphas_cumprod", t) * x - _buf(b, "sqrt_one_minus_alphas_cumprod", t) * out
+    raise ValueError(objective)
+
+
+def ddpm_sample(denoise: Callable, b: Dict[str, np.ndarray], objective: str, noise: torch.Tensor,
+                clamp: float = 300.0, trace: Optional[dict] = None) -> torch.Tensor:
+    """Ancestral sampling in the normalised space.  ``denoise(x, t_int) -> model output``."""
+    n = len(b["betas"])
+    x = noise[0].clone()
+    k = 1
+    for t in reversed(range(n)):
+        out = denoise(x, t)
+        if trace is not None:
+            trace.setdefault("x", []).append(x.clone())
+            trace.setdefault("model_out", []).append(out.clone())
+        x0 = x0_from_output(b, objective, x, out, t).clamp(-clamp, clamp)
+        mean = _buf(b, "posterior_mean_coef1", t) * x0 + _buf(b, "posterior_mean_coef2", t) * x
+        if t > 0:
+            sigma = torch.exp(0.5 * _buf(b, "posterior_log_variance_clipped", t))
+            x = mean + sigma * noise[k]
+            k += 1
+        else:
+            x = mean
+    return x
+
+
+def ddim_pairs(n_train: int, n_sample: int) -> List[tuple]:
+    """TrajRefiner.py:339-341: linspace(-1, N-1, n+1) truncated to int, reversed, paired."""
+    times = torch.linspace(-1, n_train - 1, steps=n_sample + 1).int().tolist()
+    times = list(reversed(times))
+    return list(zip(times[:-1], times[1:]))
+
+
+def ddim_sample(denoise: Callable, b: Dict[str, np.ndarray], objective: str, noise: torch.Tensor,
+                n_sample: int, eta: float = 0.0, clamp: float = 300.0, trace: Optional[dict] = None) -> torch.Tensor:
+    n = len(b["betas"])
+    x = noise[0].clone()
+    k = 1
+    for t, t_next in ddim_pairs(n, n_sample):
+        out = denoise(x, t)
+        if trace is not None:
+            trace.setdefault("x", []).append(x.clone())
+            trace.setdefault("model_out", []).append(out.clone())
+        x0 = x0_from_output(b, objective, x, out, t).clamp(-clamp, clamp)
+        # eps re-derived from the clipped x0 (for pred_noise too: rederive_pred_noise=True)
+        eps = (_buf(b, "sqrt_recip_alphas_cumprod", t) * x - x0) / _buf(b, "sqrt_recipm1_alphas_cumprod", t)
+        if t_next < 0:
+            x = x0
+            continue
+        a, a_next = _buf(b, "alphas_cumprod", t), _buf(b, "alphas_cumprod", t_next)
+        sigma = eta * ((1 - a / a_next) * (1 - a_next) / (1 - a)).sqrt()
+        c = (1 - a_next - sigma ** 2).sqrt()
+        x = x0 * a_next.sqrt() + c * eps + sigma * noise[k]
+        k += 1
+    return x
+
+
+def refiner_sample(denoise_cond: Callable, b, objective: str, transition_info, trajectory_prior, noise,
+                   residual: bool = False, auto_normalize: bool = True,
+                   n_sample: Optional[int] = None, eta: float = 0.0, trace=None) -> torch.Tensor:
+    """DiffusionWrapper.sample for one chunk.  ``denoise_cond(x, t, transition_n, prior_n) -> out``."""
+    norm = normalize if auto_normalize else (lambda v: v)
+    unnorm = denormalize if auto_normalize else (lambda v: v)
+    tra_n, pri_n = norm(transition_info), norm(trajectory_prior)
+    fn = lambda x, t: denoise_cond(x, t, tra_n, pri_n)  # noqa: E731
+    n = len(b["betas"])
+    if n_sample is None or n_sample >= n:
+        x = ddpm_sample(fn, b, objective, noise, trace=trace)
+    else:
+        x = ddim_sample(fn, b, objective, noise, n_sample, eta, trace=trace)
+    x = unnorm(x)
+    return x + trajectory_prior if residual else x
+
+
+def refiner_generate(denoise_cond: Callable, b, objective: str, maps_unused, prior_full, init_x, noise,
+                     frame_stack: int, residual: bool = False, auto_normalize: bool = True,
+                     n_sample: Optional[int] = None, eta: float = 0.0) -> torch.Tensor:
+    """Chunk loop of the generate() wrapper: (B,80,4) prior -> (B,80,4) refined trajectory.
+
+    ``noise`` is (n_chunks, n_draws, B, fs, 4).
+    """
+    B, S, C = prior_full.shape
+    if S % frame_stack:
+        raise ValueError("Number of frames must be divisible by frame stack size")
+    n_chunks = S // frame_stack
+    pri = prior_full.reshape(B, n_chunks, frame_stack, C).permute(1, 0, 2, 3)
+    transition = init_x[None].expand(B, frame_stack, C)
+    preds = []
+    for c in range(n_chunks):
+        pred = refiner_sample(denoise_cond, b, objective, transition, pri[c], noise[c], residual, auto_normalize,
+                              n_sample, eta)
+        transition = pred
+        preds.append(pred)
+    return torch.stack(preds).permute(1, 0, 2, 3).reshape(B, S, C)
+
+
+# ------------------------------------------------------------------ decoder twin (DiT path)
+def twin_sample(denoise: Callable, b: Dict[str, np.ndarray], shape, noise: Optional[torch.Tensor],
+                determin: bool = True, max_action: float = 100.0):
+    """diffusion_decoder.py:385-446.  Returns (denormalised trajectory, total_cls).
+
+    Stochastic mode draws a tensor at EVERY step (the t = 0 draw is masked out of x but
+    still enters the score), so ``noise`` holds 1 + N tensors.
+    """
+    n = len(b["betas"])
+    x = torch.zeros(shape) if determin else noise[0].clone()
+    total_cls = -(x ** 2).mean(dim=1)
+    k = 1
+    for t in reversed(range(n)):
+        out = denoise(x, t)
+        x0 = (_buf(b, "sqrt_recip_alphas_cumprod", t) * x - _buf(b, "sqrt_recipm1_alphas_cumprod", t) * out)
+        x0 = x0.clamp(-max_action, max_action)
+        mean = _buf(b, "posterior_mean_coef1", t) * x0 + _buf(b, "posterior_mean_coef2", t) * x
+        if determin:
+            z = torch.zeros(shape)
+        else:
+            z = noise[k]
+            k += 1
+        mask = 0.0 if t == 0 else 1.0
+        x = mean + mask * torch.exp(0.5 * _buf(b, "posterior_log_variance_clipped", t)) * z
+        total_cls = total_cls - (z ** 2).mean(dim=1)
+    return denormalize(x), total_cls
+
+
+# ------------------------------------------------------------------ diffusers-style steps (PARITY UNPINNED)
+def diffusers_timesteps(n_train: int, n_infer: int) -> List[int]:
+    """'leading' spacing: t_k = k * (N // n), k = n-1 ... 0."""
+    r = n_train // n_infer
+    return [k * r for k in reversed(range(n_infer))]
+
+
+def diffusers_ddpm_step(ac: np.ndarray, n_infer: int, eps, t: int, x, z, clip: bool = True, clip_range: float = 1.0):
+    n = len(ac)
+    t_prev = t - n // n_infer
+    a_t = float(ac[t])
+    a_prev = float(ac[t_prev]) if t_prev >= 0 else 1.0
+    cur_alpha = a_t / a_prev
+    cur_beta = 1 - cur_alpha
+    x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    if clip:
+        x0 = x0.clamp(-clip_range, clip_range)
+    mean = (a_prev ** 0.5 * cur_beta / (1 - a_t)) * x0 + (cur_alpha ** 0.5 * (1 - a_prev) / (1 - a_t)) * x
+    if t > 0:
+        var = max((1 - a_prev) / (1 - a_t) * cur_beta, 1e-20)
+        mean = mean + var ** 0.5 * z
+    return mean
+
+
+def diffusers_ddim_step(ac: np.ndarray, n_infer: int, eps, t: int, x, clip: bool = True, clip_range: float = 1.0):
+    """eta = 0, set_alpha_to_one=True, use_clipped_model_output=False."""
+    n = len(ac)
+    t_prev = t - n // n_infer
+    a_t = float(ac[t])
+    a_prev = float(ac[t_prev]) if t_prev >= 0 else 1.0
+    x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    if clip:
+        x0 = x0.clamp(-clip_range, clip_range)
+    return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+
+
+def explicit_generate(denoise_flat: Callable, ac: np.ndarray, n_infer: int, prior_full, init_x_flat, noise,
+                      frame_stack: int, data_mean, data_std, kind: str = "ddim") -> torch.Tensor:
+    """Flattened-chunk wrapper (ExplicitDiT.generate): chunks are (B, fs*4) vectors, horizon 1.
+
+    ``denoise_flat(x(B,1,fs*4), t, transition(B,1,fs*4), prior(B,1,fs*4)) -> (B,1,fs*4)``;
+    ``noise`` is (n_chunks, 1 + n_infer, B, 1, fs*4) (DDIM uses only element 0).
+    The prior enters un-normalised; the data_mean/std affine is applied to the
+    re-assembled output only (ExplicitDiT.py:151,193-194).
+    """
+    B, S, C = prior_full.shape
+    n_chunks = S // frame_stack
+    pri = prior_full.reshape(B, n_chunks, frame_stack * C).permute(1, 0, 2)
+    transition = init_x_flat[None].expand(B, frame_stack * C)
+    preds = []
+    for c in range(n_chunks):
+        x = noise[c, 0].clone()
+        k = 1
+        for t in diffusers_timesteps(len(ac), n_infer):
+            eps = denoise_flat(x, t, transition[:, None, :], pri[c][:, None, :])
+            if kind == "ddim":
+                x = diffusers_ddim_step(ac, n_infer, eps, t, x)
+            else:
+                x = diffusers_ddpm_step(ac, n_infer, eps, t, x, noise[c, k])
+                k += 1
+        transition = x[:, 0]
+        preds.append(transition)
+    out = torch.stack(preds).permute(1, 0, 2).reshape(B, n_chunks * frame_stack, C)
+    mean = torch.as_tensor(data_mean, dtype=torch.float32)
+    std = torch.as_tensor(data_std, dtype=torch.float32)
+    return out * std + mean
+
+
+# ------------------------------------------------------------------ metrics
+def displacement_metrics(pred: np.ndarray, label: np.ndarray) -> Dict[str, np.ndarray]:
+    """ADE/FDE at 1/3/5/8 s per scenario (trainer.py:184-234): L2 over (x, y) per point."""
+    err = np.sqrt((pred[..., 0] - label[..., 0]) ** 2 + (pred[..., 1] - label[..., 1]) ** 2)
+    return {
+        "ade1": err[:, :10].mean(1), "ade3": err[:, :30].mean(1), "ade5": err[:, :50].mean(1), "ade8": err[:, :80].mean(1),
+        "fde1": err[:, 9], "fde3": err[:, 29], "fde5": err[:, 49], "fde8": err[:, -1],
+    }

@@ -1,0 +1,352 @@
+#!/usr/bin/env python3
+"""Record golden vectors from the reference implementation.
+
+Run ONLY in the development container, where the reference tree is mounted:
+
+    PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+It imports the reference's importable modules (the in-repo ``Transformer``
+denoiser, ``TrajRefiner.DiffusionWrapper``/``TrajectoryRefiner``, the DiT /
+MM-DiT ``Transformer_TrajDiffusionModel`` and its ``DiffusionWrapper``), fills
+them with the seeded weight recipe of ``autodiffusion_amd.synth``, feeds seeded
+inputs and *host-supplied* noise (``torch.randn``/``randn_like`` are replaced by
+a queue while the reference samples) and stores inputs that cannot be
+regenerated from a seed plus every expected output as small ``.npz`` files next
+to this script.  Nothing of the reference's source is stored: only numbers.
+
+Noise order consumed by the reference loops (and reproduced by this project):
+element 0 initialises x_N, then one tensor per executed step in loop order
+(DDPM: steps t = N-1 ... 1, none at t = 0; in-repo DDIM: one per (t, t_next)
+pair with t_next >= 0, drawn even when eta = 0).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+import sys
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+warnings.filterwarnings("ignore")
+
+from autodiffusion_amd import synth  # noqa: E402
+
+from transformer4planning.models.diffusion_loss.transformer import Transformer  # noqa: E402
+from transformer4planning.models.diffusion_loss import TrajRefiner as ref_tr  # noqa: E402
+from transformer4planning.models.diffusion_loss import diffusion_decoder as ref_dd  # noqa: E402
+from transformer4planning.models.diffusion_loss.positional_embedding import SinusoidalPosEmb as PosEmbA  # noqa: E402
+from transformer4planning.libs.embeds import SinusoidalPosEmb as PosEmbB  # noqa: E402
+from transformer4planning.models import utils as ref_utils  # noqa: E402
+
+WSEED = 11      # weights
+ISEED = 7       # inputs
+NSEED = 1234    # noise
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  keys={len(out)}")
+
+
+@contextlib.contextmanager
+def noise_queue(tensors):
+    """Replace torch.randn / torch.randn_like by pops from ``tensors``."""
+    q = list(tensors)
+    real_randn, real_like = torch.randn, torch.randn_like
+
+    def randn(*shape, **kw):
+        if len(shape) == 1 and not isinstance(shape[0], int):
+            shape = tuple(shape[0])
+        t = q.pop(0)
+        assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.clone()
+
+    def randn_like(x, **kw):
+        t = q.pop(0)
+        assert tuple(t.shape) == tuple(x.shape), (t.shape, x.shape)
+        return t.clone()
+
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        yield q
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_like
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_schedules():
+    out = {}
+    for sched in ("sigmoid", "cosine", "linear"):
+        for n in (10, 50, 100, 200):
+            for obj in ("pred_noise",):
+                w = ref_tr.DiffusionWrapper(torch.nn.Identity(), timesteps=n, objective=obj, beta_schedule=sched)
+                for k, v in w.state_dict().items():
+                    out[f"{sched}_{n}_{k}"] = v
+    for obj in ("pred_x0", "pred_v"):
+        w = ref_tr.DiffusionWrapper(torch.nn.Identity(), timesteps=10, objective=obj, beta_schedule="sigmoid")
+        out[f"sigmoid_10_loss_weight_{obj}"] = w.loss_weight
+    # decoder twin keeps float64 buffers (no cast) for the cosine schedule
+    dummy = torch.nn.Identity()
+    dummy.out_features = 4
+    w = ref_dd.DiffusionWrapper(dummy, beta_schedule="cosine", n_timesteps=10)
+    for k, v in w.state_dict().items():
+        out[f"twin_cosine_10_{k}"] = v
+    save("g1_schedules", **out)
+
+
+# ----------------------------------------------------------------------------- G2/G3/G10
+def g2_g3_misc():
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 10, 4)).astype(np.float32) * 20)
+    x2 = x[..., :2].contiguous()
+    out = dict(x=x, normalize=ref_utils.normalize(x), denormalize=ref_utils.denormalize(x),
+               normalize2=ref_utils.normalize(x2), denormalize2=ref_utils.denormalize(x2))
+    for d in (32, 256, 1024):
+        t = torch.tensor([0, 1, 9, 99, 199], dtype=torch.long)
+        out[f"posemb_a_{d}"] = PosEmbA(d)(t)
+        out[f"posemb_b_{d}"] = PosEmbB(d)(t)
+    out["posemb_t"] = np.array([0, 1, 9, 99, 199])
+    out["uniform_pos_80_256"] = ref_utils.uniform_positional_embedding(80, 256)
+    out["uniform_pos_80_64"] = ref_utils.uniform_positional_embedding(80, 64)
+    save("g2_g3_misc", **out)
+
+
+# ----------------------------------------------------------------------------- G4
+def build_variant_a(fs, flattened=False, out_dim=None):
+    if flattened:
+        m = Transformer(input_dim=4 * fs, output_dim=4 * fs, horizon=1, n_cond_steps=788, cond_dim=256,
+                        n_prior_steps=1, prior_dim=4 * fs, causal_attn=True, map_cond=True)
+    else:
+        m = Transformer(input_dim=4, output_dim=out_dim or 4, horizon=fs, n_cond_steps=788, cond_dim=256,
+                        n_prior_steps=fs, prior_dim=4, causal_attn=True, map_cond=True)
+    synth.fill_module_(m, WSEED)
+    return m.eval()
+
+
+def g4_variant_a():
+    for tag, fs, flat in (("fs10", 10, False), ("fs80", 80, False), ("flat10", 10, True)):
+        m = build_variant_a(fs, flat)
+        B = 2
+        maps = synth.maps_info(B, ISEED)
+        prior = ref_utils.normalize(synth.trajectory_prior(B, ISEED))
+        if flat:
+            x = synth.noise(B, (), (1, 4 * fs), NSEED)
+            pri = prior[:, :fs].reshape(B, 1, 4 * fs)
+            tra = prior[:, fs:2 * fs].reshape(B, 1, 4 * fs)
+        else:
+            x = synth.noise(B, (), (fs, 4), NSEED)
+            pri = prior[:, :fs].contiguous()
+            tra = (prior[:, :fs] * 0.5 + 0.1).contiguous()
+        t = torch.tensor([3, 7], dtype=torch.long)
+        inter = {}
+        hooks = []
+        for i, layer in enumerate(m.encoder.layers):
+            hooks.append(layer.register_forward_hook(lambda mod, a, o, i=i: inter.__setitem__(f"enc{i}", o.detach().clone())))
+        for i, layer in enumerate(m.decoder.layers):
+            hooks.append(layer.register_forward_hook(lambda mod, a, o, i=i: inter.__setitem__(f"dec{i}", o.detach().clone())))
+        with torch.no_grad():
+            cond = dict(maps_info=maps, transition_info=tra, trajectory_prior=pri)
+            out = m(x, t, cond).reshape(B, x.shape[1], -1)
+        for h in hooks:
+            h.remove()
+        keep = {"enc0": inter["enc0"][:, :24], "memory": inter["enc1"]}
+        for i in range(4):
+            keep[f"dec{i}"] = inter[f"dec{i}"]
+        save(f"g4_variant_a_{tag}", x=x, t=t, transition_info=tra, trajectory_prior=pri, out=out, **keep)
+
+
+# ----------------------------------------------------------------------------- G5
+def dit_config(d, L, h, backbone, n_inner=None, **kw):
+    return SimpleNamespace(n_embd=d, n_inner=n_inner or 4 * d, n_head=h, n_layer=L, diffusion_backbone=backbone,
+                           debug_scenario_decoding=False, debug_scene_level_prediction=False,
+                           debug_use_adapter=False, predict_yaw=True, k=kw.get("k", 1), predict_range=80,
+                           beta_schedule="cosine", diffusion_timesteps=kw.get("n", 10), mc_num=kw.get("mc_num", 1),
+                           visualize_diffusion_intermedians=False, trajectory_loss_rescale=1.0, trajectory_dim=4)
+
+
+def build_dit(cfg):
+    m = ref_dd.Transformer_TrajDiffusionModel(cfg, out_features=4, predict_range=80)
+    synth.fill_module_(m, WSEED)
+    return m.float().eval()
+
+
+def g5_dit():
+    for tag, d, L, h in (("mini", 64, 2, 4), ("d256", 256, 4, 8)):
+        for backbone in ("DiT", "MM-DiT"):
+            cfg = dit_config(d, L, h, backbone)
+            m = build_dit(cfg)
+            B = 2
+            x = synth.noise(B, (), (80, 4), NSEED)
+            state = synth.hidden_state(B, d, ISEED)
+            t = torch.tensor([2, 9], dtype=torch.long)
+            inter = {}
+            hooks = []
+            for i, blk in enumerate(m.blocks):
+                def hook(mod, a, o, i=i):
+                    if isinstance(o, tuple):
+                        inter[f"blk{i}_x"] = o[0].detach().clone()
+                        inter[f"blk{i}_c"] = o[1].detach().clone()
+                    else:
+                        inter[f"blk{i}_x"] = o.detach().clone()
+                hooks.append(blk.register_forward_hook(hook))
+            hooks.append(m.state_encoder.register_forward_hook(lambda mod, a, o: inter.__setitem__("state_emb", o.detach().clone())))
+            hooks.append(m.x_encoder.register_forward_hook(lambda mod, a, o: inter.__setitem__("x_emb", o.detach().clone())))
+            hooks.append(m.time_encoder.register_forward_hook(lambda mod, a, o: inter.__setitem__("t_emb", o.detach().clone())))
+            with torch.no_grad():
+                out = m(x, t, state)
+            for hk in hooks:
+                hk.remove()
+            if tag == "d256":  # keep the big fixture small: first/last block, first batch row
+                keys = ("blk0_x", f"blk{L - 1}_x", f"blk{L - 1}_c", "t_emb")
+                inter = {k: v[:1] for k, v in inter.items() if k in keys}
+            save(f"g5_{backbone.replace('-', '').lower()}_{tag}", x=x, t=t, out=out, **inter)
+
+
+# ----------------------------------------------------------------------------- G6/G7
+class Recorder(torch.nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+        self.outs = []
+        self.xs = []
+
+    def forward(self, x, t, cond, **kw):
+        o = self.model(x, t, cond, **kw)
+        self.xs.append(x.detach().clone())
+        self.outs.append(o.detach().clone().reshape(x.shape[0], x.shape[1], -1))
+        return o
+
+
+def g6_g7_loops():
+    fs, B, N = 10, 2, 10
+    model = build_variant_a(fs)
+    maps = synth.maps_info(B, ISEED)
+    prior_full = synth.trajectory_prior(B, ISEED)
+    pri = prior_full[:, :fs].contiguous()
+    tra = (prior_full[:, fs:2 * fs] * 0.9).contiguous()
+    out = dict(transition_info=tra, trajectory_prior=pri)
+    for obj in ("pred_noise", "pred_x0", "pred_v"):
+        for sched in ("cosine", "sigmoid"):
+            rec = Recorder(model)
+            w = ref_tr.DiffusionWrapper(rec, timesteps=N, objective=obj, beta_schedule=sched,
+                                        auto_normalize_data=True, residual=False).eval()
+            nz = synth.noise(B, (N + 1,), (fs, 4), NSEED)
+            with noise_queue([nz[0]] + [nz[1 + i] for i in range(N - 1)]) as q:
+                cond = dict(maps_info=maps, transition_info=tra.clone(), trajectory_prior=pri.clone())
+                res = w(cond, torch.zeros(B, fs, 4))
+                assert not q
+            out[f"ddpm_{obj}_{sched}_x"] = torch.stack(rec.xs)        # x_t fed to the model at each step
+            out[f"ddpm_{obj}_{sched}_model_out"] = torch.stack(rec.outs)
+            out[f"ddpm_{obj}_{sched}_result"] = res
+    # in-repo DDIM, n=5 of N=10
+    for obj in ("pred_noise", "pred_x0"):
+        for eta in (0.0, 1.0):
+            rec = Recorder(model)
+            w = ref_tr.DiffusionWrapper(rec, timesteps=N, sampling_timesteps=5, objective=obj, beta_schedule="cosine",
+                                        ddim_sampling_eta=eta, auto_normalize_data=True, residual=False).eval()
+            assert w.is_ddim_sampling
+            nz = synth.noise(B, (6,), (fs, 4), NSEED)
+            with noise_queue([nz[0]] + [nz[1 + i] for i in range(4)]) as q:
+                cond = dict(maps_info=maps, transition_info=tra.clone(), trajectory_prior=pri.clone())
+                res = w(cond, torch.zeros(B, fs, 4))
+                assert not q
+            e = int(eta)
+            out[f"ddim_{obj}_eta{e}_x"] = torch.stack(rec.xs)
+            out[f"ddim_{obj}_eta{e}_model_out"] = torch.stack(rec.outs)
+            out[f"ddim_{obj}_eta{e}_result"] = res
+    save("g6_g7_loops", **out)
+
+
+# ----------------------------------------------------------------------------- G8
+def g8_chunk_loop():
+    """TrajectoryRefiner inside the chunk loop of the generate() wrapper.
+
+    The wrapper class itself cannot be constructed without a full STR backbone
+    config, so its eval-mode glue (chunk, expand init_x, carry the previous
+    chunk's output as transition_info, re-assemble) is driven here around the
+    reference's own TrajectoryRefiner.generate.
+    """
+    B, N = 2, 10
+    out = {}
+    for tag, fs, residual, obj, sched in (("fs10", 10, False, "pred_noise", "cosine"),
+                                          ("fs10_res", 10, True, "pred_x0", "sigmoid"),
+                                          ("fs80", 80, True, "pred_x0", "sigmoid")):
+        cfg = SimpleNamespace(trajectory_dim=4, frame_stack=fs, n_maps_token=788, maps_dim=256, map_cond=True,
+                              beta_schedule=sched, diffusion_timesteps=N, objective=obj, ddim=0.0,
+                              normalize=True, residual=residual, trajectory_loss_rescale=1.0)
+        refiner = ref_tr.TrajectoryRefiner(cfg)
+        synth.fill_module_(refiner, WSEED)
+        refiner.eval()
+        init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+        maps = synth.maps_info(B, ISEED)
+        prior = synth.trajectory_prior(B, ISEED)
+        n_chunks = 80 // fs
+        nz = synth.noise(B, (n_chunks, N + 1), (fs, 4), NSEED)
+        prior_c = prior.reshape(B, n_chunks, fs, 4).permute(1, 0, 2, 3)
+        transition = init_x[None].expand(B, fs, 4)
+        preds = []
+        for c in range(n_chunks):
+            with noise_queue([nz[c, 0]] + [nz[c, 1 + i] for i in range(N - 1)]) as q:
+                pred = refiner.generate(torch.zeros(B, fs, 4), transition, prior_c[c], maps)
+                assert not q
+            transition = pred
+            preds.append(pred)
+        final = torch.stack(preds).permute(1, 0, 2, 3).reshape(B, 80, 4)
+        out[f"{tag}_traj"] = final
+    save("g8_chunk_loop", **out)
+
+
+# ----------------------------------------------------------------------------- G9
+def g9_dit_loop():
+    out = {}
+    B, N = 2, 10
+    for backbone in ("DiT", "MM-DiT"):
+        cfg = dit_config(64, 2, 4, backbone, n=N)
+        dec = ref_dd.DiffusionDecoder(cfg)
+        synth.fill_module_(dec, WSEED)
+        dec = dec.float().eval()
+        state = synth.hidden_state(B, 64, ISEED)
+        with torch.no_grad():
+            traj_det = dec.generate(state)
+        out[f"{backbone}_determin"] = traj_det
+        nz = synth.noise(B, (N + 1,), (80, 4), NSEED)
+        # stochastic single-sample path: p_sample draws randn_like at EVERY step (masked at t=0)
+        with torch.no_grad(), noise_queue([nz[0]] + [nz[1 + i] for i in range(N)]) as q:
+            traj = dec.model(state, batch_size=B, determin=False)
+            assert not q, len(q)
+        out[f"{backbone}_stochastic"] = traj
+    save("g9_dit_loop", **out)
+
+
+def g10_metrics():
+    g = np.random.default_rng(3)
+    pred = g.standard_normal((4, 80, 4)).astype(np.float32) * 3
+    label = g.standard_normal((4, 80, 4)).astype(np.float32) * 3
+    # formulas of the evaluation metrics: per-point L2 over (x, y); horizons 1/3/5/8 s
+    err = np.sqrt((pred[..., 0] - label[..., 0]) ** 2 + (pred[..., 1] - label[..., 1]) ** 2)
+    save("g10_metrics", pred=pred, label=label,
+         ade1=err[:, :10].mean(1), ade3=err[:, :30].mean(1), ade5=err[:, :50].mean(1), ade8=err.mean(1),
+         fde1=err[:, 9], fde3=err[:, 29], fde5=err[:, 49], fde8=err[:, -1])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    g1_schedules()
+    g2_g3_misc()
+    g4_variant_a()
+    g5_dit()
+    g6_g7_loops()
+    g8_chunk_loop()
+    g9_dit_loop()
+    g10_metrics()
