@@ -1,0 +1,100 @@
+// Internal C++ interface of the HIP operator set (gfx950 only).
+//
+// Every launcher enqueues work on `stream` and returns; none allocates or
+// synchronises, so a sequence of them can be captured into a hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace adx {
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_ERF = 2, ACT_GELU_TANH = 3, ACT_LEAKY = 4, ACT_SILU = 5 };
+enum Prec : int { PREC_F32 = 0, PREC_BF16 = 1 };
+
+// Row index map: logical row m of an (M x N) operand lives at physical row
+//   (m / per_batch) * batch_stride + (m % per_batch) + off      (identity when per_batch == 0).
+// It lets a GEMM read or write "the first r rows of every batch item's S-row block"
+// or write its result into a slice of a token-concatenated buffer.
+struct RowMap {
+    int per_batch = 0, batch_stride = 0, off = 0;
+};
+
+// Y = res + gate * act(X W^T + bias + pos)        (each term optional)
+struct LinearArgs {
+    const float* X = nullptr; int64_t ldx = 0; RowMap xmap;
+    const void* W = nullptr;            // [N][K] row-major; float (PREC_F32) or bf16 bits (PREC_BF16)
+    const float* bias = nullptr;        // [N]
+    float* Y = nullptr; int64_t ldy = 0; RowMap ymap;
+    int M = 0, N = 0, K = 0;
+    int act = ACT_NONE;
+    int in_act = ACT_NONE;              // activation applied to X while it is staged (SiLU for adaLN)
+    const float* gate = nullptr; int64_t ldg = 0;   // [M][N], rows follow ymap
+    const float* res = nullptr;  int64_t ldr = 0;   // [M][N], rows follow ymap
+    const float* pos = nullptr;  int64_t ldp = 0; int pos_period = 0; int pos_off = 0;  // + pos[(m % period) + off][n]
+    // column map of Y: col n -> (n / col_group) * col_stride + (n % col_group) + col_off (identity when col_group == 0)
+    int col_group = 0, col_stride = 0, col_off = 0;
+    int prec = PREC_F32;
+};
+hipError_t linear(const LinearArgs& a, hipStream_t stream);
+
+// y = LN(x) [* gamma + beta] [* (1 + scale) + shift] [relu]; rows of length d.
+struct LayerNormArgs {
+    const float* x = nullptr; int64_t ldx = 0; RowMap xmap;
+    float* y = nullptr; int64_t ldy = 0; RowMap ymap;
+    const float* gamma = nullptr; const float* beta = nullptr;      // [d]
+    const float* shift = nullptr; const float* scale = nullptr; int64_t ldm = 0;  // [rows][d] slices, identity row map
+    const float* gate = nullptr; int64_t ldg = 0;   // y = res + gate * (...) ; [rows][d], identity row map
+    const float* res = nullptr; int64_t ldr = 0;
+    float eps = 1e-5f;
+    int rows = 0, d = 0;
+    int relu = 0;
+};
+hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream);
+
+// out[b, q, h*dv + c] = sum_j softmax_j(scale * <Q[b,q,h,:], K[b,j,h,:]>) V[b,j,h,c]
+// mask_off < 0: no mask; otherwise key j is visible to query q iff j <= q + mask_off.
+struct AttentionArgs {
+    const float* Q = nullptr; int64_t ldq = 0; int64_t q_batch_stride = 0;   // element strides
+    const float* K = nullptr; int64_t ldk = 0; int64_t k_batch_stride = 0;
+    const float* V = nullptr; int64_t ldv = 0; int64_t v_batch_stride = 0;
+    float* O = nullptr; int64_t ldo = 0; int64_t o_batch_stride = 0;
+    int B = 0, H = 0, Sq = 0, Skv = 0, dh = 0, dv = 0;
+    float scale = 1.f;
+    int mask_off = -1;
+};
+hipError_t attention(const AttentionArgs& a, hipStream_t stream);
+
+// out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
+hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);
+
+// y[r, c] = act(x[r, c] + vec[(r / rows_per_vec) * cols + c])   (rows_per_vec <= 0: one vector for all rows)
+hipError_t add_vec_act(const float* x, const float* vec, float* y, int64_t rows, int cols, int64_t rows_per_vec, int act,
+                       hipStream_t stream);
+
+// out[b * batch_stride + c] = a[b * a_stride + c] + bvec[c]   (one row per batch item, e.g. the time token)
+hipError_t set_row(float* out, int64_t batch_stride, int B, const float* a, int64_t a_stride, const float* bvec, int cols,
+                   hipStream_t stream);
+
+// trajectory normalisation: ch0 = x/25 - 1, ch1 = y/5, others copied; C channels (4 or 2)
+hipError_t normalize_traj(const float* x, float* y, int64_t n_points, int C, hipStream_t stream);
+// inverse (+1)*25, *5, ch2 := 0, ch3 copied; optional residual add
+hipError_t denormalize_traj(const float* y, const float* residual, float* x, int64_t n_points, int C, hipStream_t stream);
+// y = x * std[c] + mean[c]
+hipError_t affine_channels(const float* x, const float* mean, const float* std, float* y, int64_t n_points, int C,
+                           hipStream_t stream);
+
+// One scheduler update, elementwise over n values (see include/adx.h, adx_step_coef):
+//   x0  = clamp(a0 * x + a1 * out, -clip, clip)
+//   eps = eps_mode ? (b0 * x - x0) * b1 : out
+//   x'  = c0 * x0 + c1 * x + c2 * eps + c3 * z
+struct StepCoef { float t, a0, a1, clip, eps_mode, b0, b1, c0, c1, c2, c3, z_index; };
+hipError_t sched_step(const float* x, const float* model_out, const float* z, float* x_next, float* x0_out,
+                      int64_t n, const StepCoef* coef_dev, hipStream_t stream);
+
+// f32 -> bf16 (round to nearest even)
+hipError_t to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
+// strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)
+hipError_t copy2d(const float* src, int64_t lds, int64_t src_rows, float* dst, int64_t ldd, int64_t rows, int cols,
+                  hipStream_t stream);
+
+}  // namespace adx

@@ -1,0 +1,116 @@
+// Engine base: parameter store, activation workspace, schedule tables and hipGraph cache.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/adx.h"
+#include "adx_ops.h"
+
+namespace adx {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define ADX_HIP(call)                                   \
+    do {                                                \
+        hipError_t e__ = (call);                        \
+        if (e__ != hipSuccess) return ::adx::hip_fail(e__, #call); \
+    } while (0)
+#define ADX_TRY(call)               \
+    do {                            \
+        int rc__ = (call);          \
+        if (rc__ != ADX_OK) return rc__; \
+    } while (0)
+
+struct Param {
+    float* f32 = nullptr;
+    uint16_t* bf16 = nullptr;
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+};
+
+struct ParamSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+};
+
+}  // namespace adx
+
+// The opaque handle of the C ABI.
+struct adx_engine {
+    adx_model_config cfg{};
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, adx::Param> params;
+
+    // activation workspace (one allocation, carved by a bump pointer at reserve())
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int max_batch = 0;
+
+    // schedule
+    std::vector<adx_step_coef> steps;
+    adx::StepCoef* steps_dev = nullptr;
+    int64_t* steps_t_dev = nullptr;     // int64 timesteps, one per step
+    float* temb_table = nullptr;        // [n_steps][d_model] time-conditioning vector per step
+    int schedule_version = 0;
+
+    // graphs
+    hipStream_t cap_stream = nullptr;
+    std::map<std::string, hipGraphExec_t> graphs;
+
+    virtual ~adx_engine();
+    virtual std::vector<adx::ParamSpec> expected_params() const = 0;
+    virtual int carve_workspace(int max_batch, bool dry_run, size_t* bytes) = 0;
+    virtual int build_time_table(hipStream_t s) = 0;   // fills temb_table for the current schedule
+
+    int set_tensor(const char* name, const float* data, const int64_t* shape, int ndim);
+    int finalize();
+    int reserve(int batch);
+    int set_schedule(const adx_step_coef* steps_host, int n);
+    void drop_graphs();
+
+    // parameter access
+    const adx::Param* find(const std::string& name) const;
+    const float* P(const std::string& name) const;                         // f32 pointer (biases, gains, tables)
+    const void* W(const std::string& name, int64_t row0 = 0) const;          // GEMM operand in the engine precision
+    bool has(const std::string& name) const { return params.count(name) != 0; }
+
+    // y = act(x W[row0:row0+N]^T + b[row0:row0+N]) helper
+    adx::LinearArgs lin(const float* X, int64_t ldx, const std::string& wname, int64_t row0, int N, int K,
+                        const std::string& bname, float* Y, int64_t ldy, int M, int act = adx::ACT_NONE) const;
+
+    template <class F>
+    int run(const std::string& key, unsigned flags, hipStream_t stream, F&& body);
+};
+
+template <class F>
+int adx_engine::run(const std::string& key, unsigned flags, hipStream_t stream, F&& body) {
+    if (flags & ADX_FLAG_NO_GRAPH) return body(stream);
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+        if (!cap_stream) ADX_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        ADX_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = body(cap_stream);
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+        if (rc != ADX_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return adx::hip_fail(e, "hipStreamEndCapture");
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return adx::hip_fail(e, "hipGraphInstantiate");
+        it = graphs.emplace(key, exec).first;
+    }
+    ADX_HIP(hipGraphLaunch(it->second, stream));
+    return ADX_OK;
+}
+
+adx_engine* make_engine_a(const adx_model_config& cfg);
+adx_engine* make_engine_dit(const adx_model_config& cfg);

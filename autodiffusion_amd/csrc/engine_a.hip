@@ -1,0 +1,377 @@
+// Variant-A engine: the encoder/decoder Transformer denoiser with its DDPM/DDIM sampling loop
+// and the chunk loop of the generate() wrappers.
+//
+// Token layout of the conditioning sequence (length L = 1 + n_maps + 2P):
+//   row 0            time token        sin/cos(t) + cond_pos[0]
+//   rows 1..n_maps   map tokens        maps W_c^T + b_c + cond_pos[1+i]      (loop-invariant: built once per call)
+//   next NP rows      transition_info   tr W_p^T + b_p + cond_pos[...]        (invariant within a chunk)
+//   last NP rows      trajectory_prior  pr W_p^T + b_p + cond_pos[...]
+// Only row 0 of the encoder input changes between diffusion steps.
+//
+// With cfg.elide the engine skips work the masks make unobservable: the decoder's memory mask lets query
+// i see memory rows 0..i+1 only, so (a) cross-attention keys/values are projected for rows 0..T alone and
+// (b) the last encoder layer evaluates queries, output projection and FFN for rows 0..T alone (its keys
+// and values still cover all L rows).  Exact in real arithmetic; no summation is reordered.
+#include "engine.h"
+
+#include <math.h>
+
+using namespace adx;
+
+namespace {
+
+struct EngineA final : adx_engine {
+    int d, H, L, T, NP, Cin, Cout, Cp, nmaps, n_enc, n_dec, Lm;
+    // workspace pointers
+    float *X0 = nullptr, *XA = nullptr, *XB = nullptr, *H1 = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
+    float *Y = nullptr, *YN = nullptr, *DQKV = nullptr, *DATT = nullptr, *DFF = nullptr, *MKV = nullptr, *DQ = nullptr;
+    float *XS0 = nullptr, *XS1 = nullptr, *MOUT = nullptr, *TRAN = nullptr, *PRIN = nullptr, *TRAW = nullptr, *PRAW = nullptr,
+          *CHO = nullptr, *TE = nullptr;
+
+    explicit EngineA(const adx_model_config& c) {
+        cfg = c;
+        d = c.d_model; H = c.n_head; T = c.horizon; NP = c.n_prior_tokens; Cin = c.in_dim; Cout = c.out_dim; Cp = c.prior_dim;
+        nmaps = c.map_cond ? c.n_maps_token : 0;
+        n_enc = c.n_enc_layers; n_dec = c.n_layers;
+        L = 1 + nmaps + 2 * NP;
+        Lm = c.elide ? T + 1 : L;
+    }
+
+    std::vector<ParamSpec> expected_params() const override {
+        std::vector<ParamSpec> v;
+        auto add = [&](const std::string& n, std::vector<int64_t> s) { v.push_back({n, std::move(s)}); };
+        add("pos_emb", {1, T, d});
+        add("cond_pos_emb", {1, L, d});
+        add("input_emb.weight", {d, Cin}); add("input_emb.bias", {d});
+        if (cfg.map_cond) { add("cond_obs_emb.weight", {d, cfg.maps_dim}); add("cond_obs_emb.bias", {d}); }
+        add("prior_z_emb.weight", {d, Cp}); add("prior_z_emb.bias", {d});
+        auto mha = [&](const std::string& p) {
+            add(p + ".in_proj_weight", {3 * d, d}); add(p + ".in_proj_bias", {3 * d});
+            add(p + ".out_proj.weight", {d, d}); add(p + ".out_proj.bias", {d});
+        };
+        auto ffn = [&](const std::string& p) {
+            add(p + ".linear1.weight", {4 * d, d}); add(p + ".linear1.bias", {4 * d});
+            add(p + ".linear2.weight", {d, 4 * d}); add(p + ".linear2.bias", {d});
+        };
+        auto ln = [&](const std::string& p) { add(p + ".weight", {d}); add(p + ".bias", {d}); };
+        for (int i = 0; i < n_enc; ++i) {
+            std::string p = "encoder.layers." + std::to_string(i);
+            mha(p + ".self_attn"); ffn(p); ln(p + ".norm1"); ln(p + ".norm2");
+        }
+        for (int i = 0; i < n_dec; ++i) {
+            std::string p = "decoder.layers." + std::to_string(i);
+            mha(p + ".self_attn"); mha(p + ".multihead_attn"); ffn(p); ln(p + ".norm1"); ln(p + ".norm2"); ln(p + ".norm3");
+        }
+        ln("ln_f");
+        add("head.weight", {Cout, d}); add("head.bias", {Cout});
+        return v;
+    }
+
+    int carve_workspace(int B, bool dry, size_t* bytes) override {
+        size_t off = 0;
+        auto take = [&](float** p, size_t n) {
+            if (!dry) *p = reinterpret_cast<float*>(ws + off);
+            off += ((n * sizeof(float) + 255) / 256) * 256;
+        };
+        const size_t BL = (size_t)B * L, BT = (size_t)B * T;
+        take(&X0, BL * d); take(&XA, BL * d); take(&XB, BL * d); take(&H1, BL * d);
+        take(&QKV, BL * 3 * d); take(&ATT, BL * d); take(&FF, BL * 4 * d);
+        take(&Y, BT * d); take(&YN, BT * d); take(&DQKV, BT * 3 * d); take(&DATT, BT * d); take(&DFF, BT * 4 * d);
+        take(&MKV, (size_t)B * L * 2 * d); take(&DQ, BT * d);
+        take(&XS0, BT * Cin); take(&XS1, BT * Cin); take(&MOUT, BT * Cout);
+        take(&TRAN, (size_t)B * NP * Cp); take(&PRIN, (size_t)B * NP * Cp);
+        take(&TRAW, (size_t)B * NP * Cp); take(&PRAW, (size_t)B * NP * Cp); take(&CHO, BT * Cin);
+        take(&TE, (size_t)B * d);
+        *bytes = off;
+        return ADX_OK;
+    }
+
+    int build_time_table(hipStream_t s) override {
+        ADX_HIP(timestep_embedding(steps_t_dev, (int)steps.size(), d, temb_table, d, s));
+        return ADX_OK;
+    }
+
+    // ---------------------------------------------------------------------------------- conditioning rows
+    int embed_maps(int B, const float* maps, hipStream_t s) {
+        if (!cfg.map_cond) return ADX_OK;
+        LinearArgs a = lin(maps, cfg.maps_dim, "cond_obs_emb.weight", 0, d, cfg.maps_dim, "cond_obs_emb.bias", X0, d, B * nmaps);
+        a.ymap = RowMap{nmaps, L, 1};
+        a.pos = P("cond_pos_emb"); a.ldp = d; a.pos_period = nmaps; a.pos_off = 1;
+        ADX_HIP(linear(a, s));
+        return ADX_OK;
+    }
+
+    int embed_prior(int B, const float* tran_n, const float* prior_n, hipStream_t s) {
+        for (int which = 0; which < 2; ++which) {
+            const int off = 1 + nmaps + which * NP;
+            LinearArgs a = lin(which ? prior_n : tran_n, Cp, "prior_z_emb.weight", 0, d, Cp, "prior_z_emb.bias", X0, d, B * NP);
+            a.ymap = RowMap{NP, L, off};
+            a.pos = P("cond_pos_emb"); a.ldp = d; a.pos_period = NP; a.pos_off = off;
+            ADX_HIP(linear(a, s));
+        }
+        return ADX_OK;
+    }
+
+    // time rows: X0[b, 0, :] = te[b * te_stride : ] + cond_pos[0]
+    int set_time(int B, const float* te, int64_t te_stride, hipStream_t s) {
+        ADX_HIP(set_row(X0, (int64_t)L * d, B, te, te_stride, P("cond_pos_emb"), d, s));
+        return ADX_OK;
+    }
+
+    int ln_rows(const float* x, float* y, const std::string& p, int rows, RowMap map, hipStream_t s) {
+        LayerNormArgs a;
+        a.x = x; a.ldx = d; a.xmap = map; a.y = y; a.ldy = d; a.ymap = map;
+        a.gamma = P(p + ".weight"); a.beta = P(p + ".bias"); a.eps = 1e-5f; a.rows = rows; a.d = d;
+        ADX_HIP(layernorm(a, s));
+        return ADX_OK;
+    }
+
+    // ---------------------------------------------------------------------------------- the network
+    // X0 must hold the conditioning rows; x is (B,T,Cin); out is (B,T,Cout).
+    int run_net(int B, const float* x, float* out, hipStream_t s) {
+        const int dh = d / H;
+        const float scale = 1.0f / sqrtf((float)dh);
+        const float* cur = X0;
+        // ---- encoder (pre-norm, GELU)
+        for (int i = 0; i < n_enc; ++i) {
+            const std::string p = "encoder.layers." + std::to_string(i);
+            float* nxt = (i & 1) ? XB : XA;
+            const bool last = cfg.elide && i == n_enc - 1;
+            const int rq = last ? T + 1 : L;                      // query rows per batch item
+            const RowMap qmap = last ? RowMap{rq, L, 0} : RowMap{};
+            ADX_TRY(ln_rows(cur, H1, p + ".norm1", B * L, RowMap{}, s));
+            if (!last) {
+                ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * L), s));
+            } else {
+                LinearArgs kv = lin(H1, d, p + ".self_attn.in_proj_weight", d, 2 * d, d, p + ".self_attn.in_proj_bias", QKV + d, 3 * d, B * L);
+                ADX_HIP(linear(kv, s));
+                LinearArgs q = lin(H1, d, p + ".self_attn.in_proj_weight", 0, d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * rq);
+                q.xmap = qmap; q.ymap = qmap;
+                ADX_HIP(linear(q, s));
+            }
+            AttentionArgs at;
+            at.Q = QKV; at.ldq = 3 * d; at.q_batch_stride = (int64_t)L * 3 * d;
+            at.K = QKV + d; at.ldk = 3 * d; at.k_batch_stride = (int64_t)L * 3 * d;
+            at.V = QKV + 2 * d; at.ldv = 3 * d; at.v_batch_stride = (int64_t)L * 3 * d;
+            at.O = ATT; at.ldo = d; at.o_batch_stride = (int64_t)L * d;
+            at.B = B; at.H = H; at.Sq = rq; at.Skv = L; at.dh = dh; at.dv = dh; at.scale = scale; at.mask_off = -1;
+            ADX_HIP(attention(at, s));
+            LinearArgs o = lin(ATT, d, p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias", nxt, d, B * rq);
+            o.xmap = qmap; o.ymap = qmap; o.res = cur; o.ldr = d;
+            ADX_HIP(linear(o, s));
+            ADX_TRY(ln_rows(nxt, H1, p + ".norm2", B * rq, qmap, s));
+            LinearArgs f1 = lin(H1, d, p + ".linear1.weight", 0, 4 * d, d, p + ".linear1.bias", FF, 4 * d, B * rq, ACT_GELU_ERF);
+            f1.xmap = qmap; f1.ymap = qmap;
+            ADX_HIP(linear(f1, s));
+            LinearArgs f2 = lin(FF, 4 * d, p + ".linear2.weight", 0, d, 4 * d, p + ".linear2.bias", nxt, d, B * rq);
+            f2.xmap = qmap; f2.ymap = qmap; f2.res = nxt; f2.ldr = d;
+            ADX_HIP(linear(f2, s));
+            cur = nxt;
+        }
+        const float* memory = cur;   // (B, L, d); with elide only rows 0..T of each item are defined
+        // ---- decoder (pre-norm, GELU): causal self-attention, masked cross-attention, FFN
+        {
+            LinearArgs e = lin(x, Cin, "input_emb.weight", 0, d, Cin, "input_emb.bias", Y, d, B * T);
+            e.pos = P("pos_emb"); e.ldp = d; e.pos_period = T; e.pos_off = 0;
+            ADX_HIP(linear(e, s));
+        }
+        const RowMap mmap = RowMap{Lm, L, 0};
+        for (int i = 0; i < n_dec; ++i) {
+            const std::string p = "decoder.layers." + std::to_string(i);
+            ADX_TRY(ln_rows(Y, YN, p + ".norm1", B * T, RowMap{}, s));
+            ADX_HIP(linear(lin(YN, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", DQKV, 3 * d, B * T), s));
+            AttentionArgs sa;
+            sa.Q = DQKV; sa.K = DQKV + d; sa.V = DQKV + 2 * d;
+            sa.ldq = sa.ldk = sa.ldv = 3 * d;
+            sa.q_batch_stride = sa.k_batch_stride = sa.v_batch_stride = (int64_t)T * 3 * d;
+            sa.O = DATT; sa.ldo = d; sa.o_batch_stride = (int64_t)T * d;
+            sa.B = B; sa.H = H; sa.Sq = T; sa.Skv = T; sa.dh = dh; sa.dv = dh; sa.scale = scale; sa.mask_off = 0;
+            ADX_HIP(attention(sa, s));
+            LinearArgs o = lin(DATT, d, p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias", Y, d, B * T);
+            o.res = Y; o.ldr = d;
+            ADX_HIP(linear(o, s));
+            // cross attention
+            ADX_TRY(ln_rows(Y, YN, p + ".norm2", B * T, RowMap{}, s));
+            ADX_HIP(linear(lin(YN, d, p + ".multihead_attn.in_proj_weight", 0, d, d, p + ".multihead_attn.in_proj_bias", DQ, d, B * T), s));
+            LinearArgs kv = lin(memory, d, p + ".multihead_attn.in_proj_weight", d, 2 * d, d, p + ".multihead_attn.in_proj_bias", MKV, 2 * d, B * Lm);
+            kv.xmap = mmap;                       // memory rows 0..Lm-1 of each item -> dense (B*Lm) rows
+            ADX_HIP(linear(kv, s));
+            AttentionArgs ca;
+            ca.Q = DQ; ca.ldq = d; ca.q_batch_stride = (int64_t)T * d;
+            ca.K = MKV; ca.V = MKV + d; ca.ldk = ca.ldv = 2 * d; ca.k_batch_stride = ca.v_batch_stride = (int64_t)Lm * 2 * d;
+            ca.O = DATT; ca.ldo = d; ca.o_batch_stride = (int64_t)T * d;
+            ca.B = B; ca.H = H; ca.Sq = T; ca.Skv = Lm; ca.dh = dh; ca.dv = dh; ca.scale = scale; ca.mask_off = 1;
+            ADX_HIP(attention(ca, s));
+            LinearArgs o2 = lin(DATT, d, p + ".multihead_attn.out_proj.weight", 0, d, d, p + ".multihead_attn.out_proj.bias", Y, d, B * T);
+            o2.res = Y; o2.ldr = d;
+            ADX_HIP(linear(o2, s));
+            // FFN
+            ADX_TRY(ln_rows(Y, YN, p + ".norm3", B * T, RowMap{}, s));
+            ADX_HIP(linear(lin(YN, d, p + ".linear1.weight", 0, 4 * d, d, p + ".linear1.bias", DFF, 4 * d, B * T, ACT_GELU_ERF), s));
+            LinearArgs f2 = lin(DFF, 4 * d, p + ".linear2.weight", 0, d, 4 * d, p + ".linear2.bias", Y, d, B * T);
+            f2.res = Y; f2.ldr = d;
+            ADX_HIP(linear(f2, s));
+        }
+        ADX_TRY(ln_rows(Y, YN, "ln_f", B * T, RowMap{}, s));
+        ADX_HIP(linear(lin(YN, d, "head.weight", 0, Cout, d, "head.bias", out, Cout, B * T), s));
+        return ADX_OK;
+    }
+
+    int check_ready(int B, const char* who) {
+        if (!finalized) { set_error(std::string(who) + ": engine is not finalized"); return ADX_ESTATE; }
+        if (B <= 0) { set_error(std::string(who) + ": batch must be positive"); return ADX_EINVAL; }
+        ADX_HIP(hipSetDevice(device));
+        ADX_TRY(reserve(B));
+        return ADX_OK;
+    }
+
+    int denoise(int B, const float* x, const int64_t* t, const float* maps, const float* tran, const float* prior, float* out,
+                hipStream_t s) {
+        ADX_TRY(check_ready(B, "denoise_a"));
+        ADX_TRY(embed_maps(B, maps, s));
+        ADX_TRY(embed_prior(B, tran, prior, s));
+        ADX_HIP(timestep_embedding(t, B, d, TE, d, s));
+        ADX_TRY(set_time(B, TE, d, s));
+        return run_net(B, x, out, s);
+    }
+
+    // One chunk: transition/prior raw (B,NP,Cp); noise (n_noise,B,T,Cin); result (B,T,Cin) written with row stride ld_out.
+    int sample_body(int B, const float* tran_raw, const float* prior_raw, const float* noise, int n_noise, float* out,
+                    int64_t ld_out, float* trace_x, float* trace_out, unsigned flags, hipStream_t s) {
+        const int64_t n = (int64_t)B * T * Cin;
+        const int64_t npts_p = (int64_t)B * NP * Cp / 4;
+        const float* tn = tran_raw; const float* pn = prior_raw;
+        if (flags & ADX_FLAG_NORMALIZE) {
+            ADX_HIP(normalize_traj(tran_raw, TRAN, npts_p, 4, s));
+            ADX_HIP(normalize_traj(prior_raw, PRIN, npts_p, 4, s));
+            tn = TRAN; pn = PRIN;
+        }
+        ADX_TRY(embed_prior(B, tn, pn, s));
+        float* xc = XS0; float* xn = XS1;
+        if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, s));
+        else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, s));
+        for (size_t k = 0; k < steps.size(); ++k) {
+            ADX_TRY(set_time(B, temb_table + k * d, 0, s));
+            ADX_TRY(run_net(B, xc, MOUT, s));
+            if (trace_x) ADX_HIP(copy2d(xc, n, 0, trace_x + k * n, n, 1, (int)n, s));
+            if (trace_out) ADX_HIP(copy2d(MOUT, n, 0, trace_out + k * n, n, 1, (int)n, s));
+            const int zi = (int)steps[k].z_index;
+            const float* z = nullptr;
+            if (zi >= 0 && steps[k].c3 != 0.f) {
+                if (1 + zi >= n_noise) { set_error("sample_a: schedule draws more noise tensors than were supplied"); return ADX_EINVAL; }
+                z = noise + (int64_t)(1 + zi) * n;
+            }
+            ADX_HIP(sched_step(xc, MOUT, z, xn, nullptr, n, steps_dev + k, s));
+            float* tmp = xc; xc = xn; xn = tmp;
+        }
+        // un-normalise (+ residual) into CHO, then place the chunk
+        const float* res = xc;
+        if (flags & ADX_FLAG_NORMALIZE) {
+            ADX_HIP(denormalize_traj(xc, (flags & ADX_FLAG_RESIDUAL) ? prior_raw : nullptr, CHO, n / 4, 4, s));
+            res = CHO;
+        } else if (flags & ADX_FLAG_RESIDUAL) {
+            if (NP * Cp != T * Cin) { set_error("sample_a: residual needs prior and sample of the same size"); return ADX_EINVAL; }
+            ADX_HIP(add_vec_act(xc, prior_raw, CHO, B, T * Cin, 1, ACT_NONE, s));
+            res = CHO;
+        }
+        ADX_HIP(copy2d(res, (int64_t)T * Cin, 0, out, ld_out, B, T * Cin, s));
+        return ADX_OK;
+    }
+
+    int validate_sampling(int n_noise, const char* who) {
+        if (steps.empty()) { set_error(std::string(who) + ": no schedule set"); return ADX_ESTATE; }
+        if (Cin != Cout) { set_error(std::string(who) + ": sampling needs in_dim == out_dim"); return ADX_EINVAL; }
+        if ((Cin % 4) || (Cp % 4)) { set_error(std::string(who) + ": channel counts must be multiples of 4"); return ADX_EINVAL; }
+        if (n_noise < 0) { set_error(std::string(who) + ": negative noise count"); return ADX_EINVAL; }
+        return ADX_OK;
+    }
+
+    int sample(int B, const float* maps, const float* tran, const float* prior, const float* noise, int n_noise, float* out,
+               float* trace_x, float* trace_out, unsigned flags, hipStream_t s) {
+        ADX_TRY(check_ready(B, "sample_a"));
+        ADX_TRY(validate_sampling(n_noise, "sample_a"));
+        char key[256];
+        snprintf(key, sizeof key, "s|%d|%p|%p|%p|%p|%d|%p|%p|%p|%u|%d", B, (const void*)maps, (const void*)tran, (const void*)prior,
+                 (const void*)noise, n_noise, (void*)out, (void*)trace_x, (void*)trace_out, flags, schedule_version);
+        return run(key, flags, s, [&](hipStream_t cs) -> int {
+            ADX_TRY(embed_maps(B, maps, cs));
+            return sample_body(B, tran, prior, noise, n_noise, out, (int64_t)T * Cin, trace_x, trace_out, flags, cs);
+        });
+    }
+
+    int generate(int B, int S, int fs, const float* maps, const float* prior_full, const float* init_x, const float* noise,
+                 int n_noise, float* out, unsigned flags, hipStream_t s) {
+        ADX_TRY(check_ready(B, "generate_a"));
+        ADX_TRY(validate_sampling(n_noise, "generate_a"));
+        if (fs <= 0 || S % fs) { set_error("Number of frames must be divisible by frame stack size"); return ADX_EINVAL; }
+        if (fs * 4 != T * Cin || NP * Cp != fs * 4) { set_error("generate_a: frame_stack does not match the engine's token layout"); return ADX_EINVAL; }
+        const int n_chunks = S / fs;
+        const int chunk = fs * 4;                       // floats per batch item per chunk
+        char key[256];
+        snprintf(key, sizeof key, "g|%d|%d|%d|%p|%p|%p|%p|%d|%p|%u|%d", B, S, fs, (const void*)maps, (const void*)prior_full,
+                 (const void*)init_x, (const void*)noise, n_noise, (void*)out, flags, schedule_version);
+        return run(key, flags, s, [&](hipStream_t cs) -> int {
+            ADX_TRY(embed_maps(B, maps, cs));
+            for (int c = 0; c < n_chunks; ++c) {
+                ADX_HIP(copy2d(prior_full + (int64_t)c * chunk, (int64_t)S * 4, 0, PRAW, chunk, B, chunk, cs));
+                if (c == 0) ADX_HIP(copy2d(init_x, chunk, 1, TRAW, chunk, B, chunk, cs));
+                else ADX_HIP(copy2d(out + (int64_t)(c - 1) * chunk, (int64_t)S * 4, 0, TRAW, chunk, B, chunk, cs));
+                const float* nz = noise ? noise + (int64_t)c * n_noise * B * chunk : nullptr;
+                ADX_TRY(sample_body(B, TRAW, PRAW, nz, n_noise, out + (int64_t)c * chunk, (int64_t)S * 4, nullptr, nullptr, flags, cs));
+            }
+            return ADX_OK;
+        });
+    }
+};
+
+}  // namespace
+
+adx_engine* make_engine_a(const adx_model_config& cfg) {
+    if (cfg.n_prior_tokens <= 0 || cfg.prior_dim <= 0 || cfg.n_enc_layers <= 0) {
+        set_error("engine_create: variant A needs n_prior_tokens, prior_dim and n_enc_layers > 0");
+        return nullptr;
+    }
+    if (cfg.map_cond && (cfg.n_maps_token <= 0 || cfg.maps_dim <= 0)) {
+        set_error("engine_create: map_cond needs n_maps_token and maps_dim");
+        return nullptr;
+    }
+    const int dh = cfg.d_model / cfg.n_head;
+    if (dh != 4 && dh != 8 && dh != 16 && cfg.n_maps_token + 2 * cfg.n_prior_tokens + 1 > 800) {
+        set_error("engine_create: variant A with head_dim outside {4,8,16} supports at most 800 conditioning tokens");
+        return nullptr;
+    }
+    return new EngineA(cfg);
+}
+
+#define ADX_API extern "C" __attribute__((visibility("default")))
+
+static EngineA* as_a(adx_engine* e, const char* who) {
+    if (!e || e->cfg.variant != ADX_VARIANT_A) { set_error(std::string(who) + ": not a variant-A engine"); return nullptr; }
+    return static_cast<EngineA*>(e);
+}
+
+ADX_API int adx_denoise_a(adx_engine* e, int B, const float* x, const int64_t* t, const float* maps, const float* transition,
+                          const float* prior, float* out, void* stream) {
+    EngineA* a = as_a(e, "denoise_a");
+    if (!a) return ADX_EINVAL;
+    if (!x || !t || !transition || !prior || !out || (a->cfg.map_cond && !maps)) { set_error("denoise_a: null pointer"); return ADX_EINVAL; }
+    return a->denoise(B, x, t, maps, transition, prior, out, (hipStream_t)stream);
+}
+
+ADX_API int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transition, const float* prior, const float* noise,
+                         int n_noise, float* out, float* trace_x, float* trace_out, unsigned flags, void* stream) {
+    EngineA* a = as_a(e, "sample_a");
+    if (!a) return ADX_EINVAL;
+    if (!transition || !prior || !out || (a->cfg.map_cond && !maps)) { set_error("sample_a: null pointer"); return ADX_EINVAL; }
+    if (!noise && !(flags & ADX_FLAG_INIT_ZERO)) { set_error("sample_a: noise is required unless ADX_FLAG_INIT_ZERO"); return ADX_EINVAL; }
+    return a->sample(B, maps, transition, prior, noise, n_noise, out, trace_x, trace_out, flags, (hipStream_t)stream);
+}
+
+ADX_API int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
+                           const float* init_x, const float* noise, int n_noise, float* out, unsigned flags, void* stream) {
+    EngineA* a = as_a(e, "generate_a");
+    if (!a) return ADX_EINVAL;
+    if (!prior_full || !init_x || !out || (a->cfg.map_cond && !maps)) { set_error("generate_a: null pointer"); return ADX_EINVAL; }
+    if (!noise && !(flags & ADX_FLAG_INIT_ZERO)) { set_error("generate_a: noise is required unless ADX_FLAG_INIT_ZERO"); return ADX_EINVAL; }
+    return a->generate(B, S, frame_stack, maps, prior_full, init_x, noise, n_noise, out, flags, (hipStream_t)stream);
+}

@@ -1,0 +1,274 @@
+// Engine base implementation and the extern "C" surface of libadx.so.
+#include "engine.h"
+
+#include <stdio.h>
+#include <string.h>
+
+namespace adx {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return ADX_EHIP;
+}
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+}  // namespace adx
+
+using namespace adx;
+
+// ------------------------------------------------------------------------------------------ engine base
+adx_engine::~adx_engine() {
+    drop_graphs();
+    for (auto& kv : params) {
+        if (kv.second.f32) (void)hipFree(kv.second.f32);
+        if (kv.second.bf16) (void)hipFree(kv.second.bf16);
+    }
+    if (ws) (void)hipFree(ws);
+    if (steps_dev) (void)hipFree(steps_dev);
+    if (steps_t_dev) (void)hipFree(steps_t_dev);
+    if (temb_table) (void)hipFree(temb_table);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+}
+
+void adx_engine::drop_graphs() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear();
+}
+
+const Param* adx_engine::find(const std::string& name) const {
+    auto it = params.find(name);
+    return it == params.end() ? nullptr : &it->second;
+}
+
+const float* adx_engine::P(const std::string& name) const {
+    const Param* p = find(name);
+    return p ? p->f32 : nullptr;
+}
+
+const void* adx_engine::W(const std::string& name, int64_t row0) const {
+    const Param* p = find(name);
+    if (!p) return nullptr;
+    const int64_t K = p->shape.back();
+    if (cfg.precision == ADX_PREC_BF16) return p->bf16 + row0 * K;
+    return p->f32 + row0 * K;
+}
+
+LinearArgs adx_engine::lin(const float* X, int64_t ldx, const std::string& wname, int64_t row0, int N, int K,
+                           const std::string& bname, float* Y, int64_t ldy, int M, int act) const {
+    LinearArgs a;
+    a.X = X; a.ldx = ldx;
+    a.W = W(wname, row0);
+    a.bias = bname.empty() ? nullptr : P(bname) + row0;
+    a.Y = Y; a.ldy = ldy;
+    a.M = M; a.N = N; a.K = K;
+    a.act = act;
+    a.prec = cfg.precision;
+    return a;
+}
+
+int adx_engine::set_tensor(const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!name || !data || !shape || ndim < 1 || ndim > 4) return fail(ADX_EINVAL, "set_tensor: bad argument");
+    int64_t numel = 1;
+    std::vector<int64_t> shp(shape, shape + ndim);
+    for (int64_t s : shp) {
+        if (s <= 0) return fail(ADX_EINVAL, std::string("set_tensor: non-positive dimension in ") + name);
+        numel *= s;
+    }
+    ADX_HIP(hipSetDevice(device));
+    Param& p = params[name];
+    if (p.numel != numel) {
+        if (p.f32) (void)hipFree(p.f32);
+        if (p.bf16) (void)hipFree(p.bf16);
+        p.f32 = nullptr; p.bf16 = nullptr;
+        ADX_HIP(hipMalloc(&p.f32, sizeof(float) * numel));
+        if (ndim >= 2) ADX_HIP(hipMalloc(&p.bf16, sizeof(uint16_t) * numel));
+        drop_graphs();                      // captured graphs hold the old addresses
+    }
+    p.shape = shp;
+    p.numel = numel;
+    ADX_HIP(hipMemcpyAsync(p.f32, data, sizeof(float) * numel, hipMemcpyDeviceToDevice, nullptr));
+    if (p.bf16) ADX_HIP(to_bf16(p.f32, p.bf16, numel, nullptr));
+    finalized = false;
+    return ADX_OK;
+}
+
+int adx_engine::finalize() {
+    for (const ParamSpec& s : expected_params()) {
+        const Param* p = find(s.name);
+        if (!p) return fail(ADX_ENOTFOUND, "finalize: missing parameter '" + s.name + "'");
+        if (p->shape != s.shape) {
+            std::string got, want;
+            for (int64_t v : p->shape) got += std::to_string(v) + ",";
+            for (int64_t v : s.shape) want += std::to_string(v) + ",";
+            return fail(ADX_EINVAL, "finalize: parameter '" + s.name + "' has shape [" + got + "] expected [" + want + "]");
+        }
+    }
+    ADX_HIP(hipStreamSynchronize(nullptr));
+    finalized = true;
+    return ADX_OK;
+}
+
+int adx_engine::reserve(int batch) {
+    if (batch <= 0) return fail(ADX_EINVAL, "reserve: batch must be positive");
+    if (batch <= max_batch && ws) return ADX_OK;
+    ADX_HIP(hipSetDevice(device));
+    size_t bytes = 0;
+    ADX_TRY(carve_workspace(batch, true, &bytes));
+    drop_graphs();
+    if (ws) { ADX_HIP(hipDeviceSynchronize()); (void)hipFree(ws); ws = nullptr; }
+    hipError_t e = hipMalloc(&ws, bytes);
+    if (e != hipSuccess) {
+        ws = nullptr; ws_bytes = 0; max_batch = 0;
+        return fail(ADX_ENOMEM, "reserve: hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
+    ws_bytes = bytes;
+    max_batch = batch;
+    return carve_workspace(batch, false, &bytes);
+}
+
+int adx_engine::set_schedule(const adx_step_coef* s, int n) {
+    if (!s || n <= 0 || n > 100000) return fail(ADX_EINVAL, "set_schedule: bad argument");
+    if (!finalized) return fail(ADX_ESTATE, "set_schedule: engine is not finalized");
+    ADX_HIP(hipSetDevice(device));
+    drop_graphs();
+    steps.assign(s, s + n);
+    if (steps_dev) (void)hipFree(steps_dev);
+    if (steps_t_dev) (void)hipFree(steps_t_dev);
+    if (temb_table) (void)hipFree(temb_table);
+    steps_dev = nullptr; steps_t_dev = nullptr; temb_table = nullptr;
+    static_assert(sizeof(StepCoef) == sizeof(adx_step_coef), "coefficient layouts must match");
+    ADX_HIP(hipMalloc(&steps_dev, sizeof(StepCoef) * n));
+    ADX_HIP(hipMalloc(&steps_t_dev, sizeof(int64_t) * n));
+    ADX_HIP(hipMalloc(&temb_table, sizeof(float) * (size_t)n * cfg.d_model));
+    std::vector<int64_t> tt(n);
+    for (int i = 0; i < n; ++i) tt[i] = (int64_t)s[i].t;
+    ADX_HIP(hipMemcpy(steps_dev, s, sizeof(StepCoef) * n, hipMemcpyHostToDevice));
+    ADX_HIP(hipMemcpy(steps_t_dev, tt.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
+    ++schedule_version;
+    ADX_TRY(build_time_table(nullptr));
+    ADX_HIP(hipStreamSynchronize(nullptr));
+    return ADX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+#define ADX_API extern "C" __attribute__((visibility("default")))
+
+ADX_API int adx_abi_version(void) { return ADX_ABI_VERSION; }
+ADX_API const char* adx_last_error(void) { return g_err.c_str(); }
+
+static int done(hipError_t e, const char* what) { return e == hipSuccess ? ADX_OK : hip_fail(e, what); }
+
+ADX_API int adx_op_timestep_embedding(const int64_t* t, int n, int dim, float* out, void* stream) {
+    if (!t || !out) return fail(ADX_EINVAL, "timestep_embedding: null pointer");
+    return done(timestep_embedding(t, n, dim, out, dim, (hipStream_t)stream), "timestep_embedding");
+}
+
+ADX_API int adx_op_linear(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
+                          int prec, void* stream) {
+    if (!x || !w || !y) return fail(ADX_EINVAL, "linear: null pointer");
+    if (prec != ADX_PREC_F32 && prec != ADX_PREC_BF16) return fail(ADX_EINVAL, "linear: unknown precision");
+    LinearArgs a;
+    a.X = x; a.ldx = K; a.W = w; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
+    return done(linear(a, (hipStream_t)stream), "linear");
+}
+
+ADX_API int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
+    if (!x || !y) return fail(ADX_EINVAL, "to_bf16: null pointer");
+    return done(to_bf16(x, y, n, (hipStream_t)stream), "to_bf16");
+}
+
+ADX_API int adx_op_layernorm(const float* x, const float* gamma, const float* beta, const float* shift, const float* scale,
+                             int64_t ld_mod, float eps, int relu, int64_t rows, int d, float* y, void* stream) {
+    if (!x || !y) return fail(ADX_EINVAL, "layernorm: null pointer");
+    if ((gamma == nullptr) != (beta == nullptr) || (shift == nullptr) != (scale == nullptr))
+        return fail(ADX_EINVAL, "layernorm: gamma/beta and shift/scale come in pairs");
+    LayerNormArgs a;
+    a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.gamma = gamma; a.beta = beta; a.shift = shift; a.scale = scale; a.ldm = ld_mod;
+    a.eps = eps; a.rows = (int)rows; a.d = d; a.relu = relu;
+    return done(layernorm(a, (hipStream_t)stream), "layernorm");
+}
+
+ADX_API int adx_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh,
+                             int dv, float scale, int mask_off, void* stream) {
+    if (!q || !k || !v || !o) return fail(ADX_EINVAL, "attention: null pointer");
+    AttentionArgs a;
+    a.Q = q; a.ldq = (int64_t)H * dh; a.q_batch_stride = (int64_t)Sq * H * dh;
+    a.K = k; a.ldk = (int64_t)H * dh; a.k_batch_stride = (int64_t)Skv * H * dh;
+    a.V = v; a.ldv = (int64_t)H * dv; a.v_batch_stride = (int64_t)Skv * H * dv;
+    a.O = o; a.ldo = (int64_t)H * dv; a.o_batch_stride = (int64_t)Sq * H * dv;
+    a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.dh = dh; a.dv = dv; a.scale = scale; a.mask_off = mask_off;
+    hipError_t e = attention(a, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(ADX_EINVAL, "attention: unsupported shape");
+    return done(e, "attention");
+}
+
+ADX_API int adx_op_normalize(const float* x, float* y, int64_t n_points, int C, void* stream) {
+    if (!x || !y || (C != 2 && C != 4)) return fail(ADX_EINVAL, "normalize: bad argument");
+    return done(normalize_traj(x, y, n_points, C, (hipStream_t)stream), "normalize");
+}
+
+ADX_API int adx_op_denormalize(const float* y, const float* residual, float* x, int64_t n_points, int C, void* stream) {
+    if (!x || !y || (C != 2 && C != 4)) return fail(ADX_EINVAL, "denormalize: bad argument");
+    return done(denormalize_traj(y, residual, x, n_points, C, (hipStream_t)stream), "denormalize");
+}
+
+ADX_API int adx_op_sched_step(const float* x, const float* model_out, const float* z, float* x_next, float* x0_out, int64_t n,
+                              const adx_step_coef* coef_dev, void* stream) {
+    if (!x || !model_out || !x_next || !coef_dev) return fail(ADX_EINVAL, "sched_step: null pointer");
+    return done(sched_step(x, model_out, z, x_next, x0_out, n, reinterpret_cast<const StepCoef*>(coef_dev), (hipStream_t)stream),
+                "sched_step");
+}
+
+ADX_API int adx_engine_create(const adx_model_config* cfg, adx_engine** out) {
+    if (!cfg || !out) return fail(ADX_EINVAL, "engine_create: null pointer");
+    if (cfg->precision != ADX_PREC_F32 && cfg->precision != ADX_PREC_BF16) return fail(ADX_EINVAL, "engine_create: unknown precision");
+    if (cfg->d_model <= 0 || cfg->n_head <= 0 || cfg->d_model % cfg->n_head) return fail(ADX_EINVAL, "engine_create: d_model must be a positive multiple of n_head");
+    if (cfg->horizon <= 0 || cfg->in_dim <= 0 || cfg->out_dim <= 0 || cfg->n_layers <= 0) return fail(ADX_EINVAL, "engine_create: bad dimensions");
+    adx_engine* e = nullptr;
+    if (cfg->variant == ADX_VARIANT_A) e = make_engine_a(*cfg);
+    else if (cfg->variant == ADX_VARIANT_DIT || cfg->variant == ADX_VARIANT_MMDIT) e = make_engine_dit(*cfg);
+    else return fail(ADX_EINVAL, "engine_create: unknown variant");
+    if (!e) return ADX_EINVAL;   // message set by the factory
+    hipError_t he = hipGetDevice(&e->device);
+    if (he != hipSuccess) { delete e; return hip_fail(he, "hipGetDevice"); }
+    *out = e;
+    return ADX_OK;
+}
+
+ADX_API int adx_engine_destroy(adx_engine* e) {
+    if (!e) return ADX_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    delete e;
+    return ADX_OK;
+}
+
+ADX_API int adx_engine_set_tensor(adx_engine* e, const char* name, const float* data, const int64_t* shape_host, int ndim) {
+    if (!e) return fail(ADX_EINVAL, "set_tensor: null engine");
+    return e->set_tensor(name, data, shape_host, ndim);
+}
+
+ADX_API int adx_engine_finalize(adx_engine* e) {
+    if (!e) return fail(ADX_EINVAL, "finalize: null engine");
+    return e->finalize();
+}
+
+ADX_API int adx_engine_reserve(adx_engine* e, int max_batch) {
+    if (!e) return fail(ADX_EINVAL, "reserve: null engine");
+    return e->reserve(max_batch);
+}
+
+ADX_API int64_t adx_engine_workspace_bytes(const adx_engine* e) { return e ? (int64_t)e->ws_bytes : 0; }
+
+ADX_API int adx_engine_set_schedule(adx_engine* e, const adx_step_coef* steps_host, int n_steps) {
+    if (!e) return fail(ADX_EINVAL, "set_schedule: null engine");
+    return e->set_schedule(steps_host, n_steps);
+}

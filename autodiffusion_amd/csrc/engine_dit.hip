@@ -1,0 +1,343 @@
+// Variant-B engine: the DiT / MM-DiT trajectory denoiser and its DDPM sampling loop.
+//
+// Loop-invariant work is done once per call: state_encoder(state) and, per schedule, the time-encoder MLP
+// of every step (timesteps are uniform over the batch while sampling, so the time conditioning is one
+// d-vector per step).  Per step: x_encoder (four residual-concat MLP stages), adaLN modulation, the blocks,
+// the final layer and the scheduler update.
+//
+// Residual-concat stage (DecoderResCat): fc(cat[x, relu(LN(W x + b))]).  The concatenation is never copied:
+// every stage owns a buffer of width in+hidden whose left columns are written by the previous stage's fc
+// GEMM and whose right columns are written by the LayerNorm kernel.
+#include "engine.h"
+
+#include <math.h>
+
+#include <algorithm>
+
+using namespace adx;
+
+namespace {
+
+struct Stage { std::string name; int hidden, in, out; };
+
+struct EngineDiT final : adx_engine {
+    int d, H, NL, S, C, n_inner, connect;
+    bool mm;
+    std::vector<Stage> s_stages, x_stages;
+    // workspace
+    std::vector<float*> s_cat, x_cat;
+    float *HT = nullptr, *SE = nullptr, *HX = nullptr, *CC = nullptr, *SIL = nullptr, *MOD = nullptr, *MODC = nullptr, *HN = nullptr,
+          *HN2 = nullptr, *QB = nullptr, *KB = nullptr, *VB = nullptr, *ATT = nullptr, *Z0 = nullptr, *Z1 = nullptr, *FF = nullptr,
+          *OB = nullptr, *XA = nullptr, *CA = nullptr, *MODF = nullptr, *XS0 = nullptr, *XS1 = nullptr, *MOUT = nullptr, *TEB = nullptr,
+          *TEH1 = nullptr, *TEH2 = nullptr;
+
+    explicit EngineDiT(const adx_model_config& c) {
+        cfg = c;
+        d = c.d_model; H = c.n_head; NL = c.n_layers; S = c.horizon; C = c.in_dim;
+        n_inner = c.n_inner; connect = c.connect_dim;
+        mm = c.variant == ADX_VARIANT_MMDIT;
+        s_stages = {{"state_encoder.0", n_inner, d, connect}, {"state_encoder.1", 2 * connect, connect, d}};
+        x_stages = {{"x_encoder.0", 64, C, 128}, {"x_encoder.1", 256, 128, 512}, {"x_encoder.2", 1024, 512, 768},
+                    {"x_encoder.3", 2048, 768, d}};
+    }
+
+    std::vector<ParamSpec> expected_params() const override {
+        std::vector<ParamSpec> v;
+        auto add = [&](const std::string& n, std::vector<int64_t> s) { v.push_back({n, std::move(s)}); };
+        auto lin2 = [&](const std::string& p, int o, int i) { add(p + ".weight", {o, i}); add(p + ".bias", {o}); };
+        add("position_embedding", {1, S, d});
+        for (const auto* st : {&s_stages, &x_stages})
+            for (const Stage& g : *st) {
+                lin2(g.name + ".mlp.linear", g.hidden, g.in);
+                add(g.name + ".mlp.layer_norm.weight", {g.hidden}); add(g.name + ".mlp.layer_norm.bias", {g.hidden});
+                lin2(g.name + ".fc", g.out, g.hidden + g.in);
+            }
+        lin2("time_encoder.1", 2 * d, d); lin2("time_encoder.3", 2 * d, 2 * d); lin2("time_encoder.5", d, 2 * d);
+        for (int i = 0; i < NL; ++i) {
+            const std::string p = "blocks." + std::to_string(i);
+            if (!mm) {
+                add(p + ".attn.self_attn.in_proj_weight", {3 * d, d}); add(p + ".attn.self_attn.in_proj_bias", {3 * d});
+                lin2(p + ".attn.self_attn.out_proj", d, d);
+                lin2(p + ".attn.linear1", 4 * d, d); lin2(p + ".attn.linear2", d, 4 * d);
+                add(p + ".attn.norm1.weight", {d}); add(p + ".attn.norm1.bias", {d});
+                add(p + ".attn.norm2.weight", {d}); add(p + ".attn.norm2.bias", {d});
+                lin2(p + ".mlp.0", 4 * d, d); lin2(p + ".mlp.2", d, 4 * d);
+                lin2(p + ".adaLN_modulation.1", 6 * d, d);
+            } else {
+                for (const char* sfx : {"x", "c"}) {
+                    const std::string q = sfx;
+                    lin2(p + ".adaLN_modulation_" + q + ".1", 6 * d, d);
+                    lin2(p + ".linear_" + q + ".0", d, d);
+                    lin2(p + ".mlp_" + q + ".0", 4 * d, d); lin2(p + ".mlp_" + q + ".2", d, 4 * d);
+                    for (const char* w : {"Wq_", "Wk_", "Wv_"}) add(p + ".attn." + w + q + ".weight", {(int64_t)d * H, d});
+                }
+                lin2(p + ".attn.proj", d, 2 * d * H);
+            }
+        }
+        lin2("final_layer.linear", C, d);
+        lin2("final_layer.adaLN_modulation.1", 2 * d, d);
+        return v;
+    }
+
+    int carve_workspace(int B, bool dry, size_t* bytes) override {
+        size_t off = 0;
+        auto take = [&](float** p, size_t n) {
+            if (!dry) *p = reinterpret_cast<float*>(ws + off);
+            off += ((n * sizeof(float) + 255) / 256) * 256;
+        };
+        const size_t R = (size_t)B * S;
+        int maxh = 0;
+        s_cat.resize(s_stages.size()); x_cat.resize(x_stages.size());
+        for (size_t i = 0; i < s_stages.size(); ++i) { take(&s_cat[i], R * (s_stages[i].in + s_stages[i].hidden)); maxh = std::max(maxh, s_stages[i].hidden); }
+        for (size_t i = 0; i < x_stages.size(); ++i) { take(&x_cat[i], R * (x_stages[i].in + x_stages[i].hidden)); maxh = std::max(maxh, x_stages[i].hidden); }
+        take(&HT, R * maxh);
+        take(&SE, R * d); take(&HX, R * d); take(&SIL, R * d); take(&MOD, R * 6 * d); take(&HN, R * d);
+        take(&FF, R * 4 * d); take(&MODF, R * 2 * d);
+        if (!mm) {
+            take(&QB, R * 3 * d); take(&ATT, R * d); take(&Z0, R * d); take(&Z1, R * d);
+        } else {
+            take(&CC, R * d); take(&MODC, R * 6 * d); take(&HN2, R * d);
+            take(&QB, R * 2 * d * H); take(&KB, R * 2 * d * H); take(&VB, R * 2 * d * H); take(&ATT, R * 2 * d * H);
+            take(&OB, R * d); take(&XA, R * d); take(&CA, R * d);
+        }
+        take(&XS0, R * C); take(&XS1, R * C); take(&MOUT, R * C);
+        take(&TEB, (size_t)B * d); take(&TEH1, (size_t)std::max(B, 4096) * 2 * d); take(&TEH2, (size_t)std::max(B, 4096) * 2 * d);
+        *bytes = off;
+        return ADX_OK;
+    }
+
+    // time_encoder on n rows of int64 timesteps -> out (n, d).  Scratch: TEH1/TEH2 (n, 2d).
+    int time_encoder(const int64_t* t, int n, float* out, float* h1, float* h2, hipStream_t s) {
+        ADX_HIP(timestep_embedding(t, n, d, out, d, s));
+        ADX_HIP(linear(lin(out, d, "time_encoder.1.weight", 0, 2 * d, d, "time_encoder.1.bias", h1, 2 * d, n, ACT_LEAKY), s));
+        ADX_HIP(linear(lin(h1, 2 * d, "time_encoder.3.weight", 0, 2 * d, 2 * d, "time_encoder.3.bias", h2, 2 * d, n, ACT_LEAKY), s));
+        ADX_HIP(linear(lin(h2, 2 * d, "time_encoder.5.weight", 0, d, 2 * d, "time_encoder.5.bias", out, d, n), s));
+        return ADX_OK;
+    }
+
+    int build_time_table(hipStream_t s) override {
+        const int n = (int)steps.size();
+        float *h1 = nullptr, *h2 = nullptr;
+        ADX_HIP(hipMalloc(&h1, sizeof(float) * (size_t)n * 2 * d));
+        ADX_HIP(hipMalloc(&h2, sizeof(float) * (size_t)n * 2 * d));
+        int rc = time_encoder(steps_t_dev, n, temb_table, h1, h2, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(h1); (void)hipFree(h2);
+        return rc;
+    }
+
+    // chain of residual-concat stages; input already sits in cat[0][:, :in0]; last fc writes `out` (+ pos)
+    int run_stages(const std::vector<Stage>& st, std::vector<float*>& cat, int R, float* out, const float* pos, hipStream_t s) {
+        for (size_t i = 0; i < st.size(); ++i) {
+            const Stage& g = st[i];
+            const int ld = g.in + g.hidden;
+            ADX_HIP(linear(lin(cat[i], ld, g.name + ".mlp.linear.weight", 0, g.hidden, g.in, g.name + ".mlp.linear.bias", HT, g.hidden, R), s));
+            LayerNormArgs ln;
+            ln.x = HT; ln.ldx = g.hidden; ln.y = cat[i] + g.in; ln.ldy = ld;
+            ln.gamma = P(g.name + ".mlp.layer_norm.weight"); ln.beta = P(g.name + ".mlp.layer_norm.bias");
+            ln.eps = 1e-5f; ln.rows = R; ln.d = g.hidden; ln.relu = 1;
+            ADX_HIP(layernorm(ln, s));
+            const bool lastst = i + 1 == st.size();
+            float* y = lastst ? out : cat[i + 1];
+            const int ldy = lastst ? g.out : st[i + 1].in + st[i + 1].hidden;
+            LinearArgs fc = lin(cat[i], ld, g.name + ".fc.weight", 0, g.out, ld, g.name + ".fc.bias", y, ldy, R);
+            if (lastst && pos) { fc.pos = pos; fc.ldp = g.out; fc.pos_period = S; fc.pos_off = 0; }
+            ADX_HIP(linear(fc, s));
+        }
+        return ADX_OK;
+    }
+
+    int encode_state(int B, const float* state, hipStream_t s) {
+        const int R = B * S;
+        ADX_HIP(copy2d(state, d, 0, s_cat[0], s_stages[0].in + s_stages[0].hidden, R, d, s));
+        return run_stages(s_stages, s_cat, R, SE, nullptr, s);
+    }
+
+    int ln_mod(const float* x, float* y, const float* mod, int ld_mod, int shift_chunk, int R, hipStream_t s) {
+        LayerNormArgs a;
+        a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.eps = 1e-6f; a.rows = R; a.d = d;
+        a.shift = mod + (int64_t)shift_chunk * d; a.scale = mod + (int64_t)(shift_chunk + 1) * d; a.ldm = ld_mod;
+        ADX_HIP(layernorm(a, s));
+        return ADX_OK;
+    }
+
+    int ln_affine(const float* x, float* y, const std::string& p, int R, const float* gate, int ldg, const float* res, hipStream_t s) {
+        LayerNormArgs a;
+        a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.eps = 1e-5f; a.rows = R; a.d = d;
+        a.gamma = P(p + ".weight"); a.beta = P(p + ".bias");
+        a.gate = gate; a.ldg = ldg; a.res = res; a.ldr = d;
+        ADX_HIP(layernorm(a, s));
+        return ADX_OK;
+    }
+
+    // One denoiser evaluation.  x (B,S,C); te: time conditioning (rows_per_vec = S: one vector per batch item,
+    // 0: one vector for all); SE must hold state_encoder(state).  out (B,S,C).
+    int run_net(int B, const float* x, const float* te, int64_t rows_per_vec, float* out, hipStream_t s) {
+        const int R = B * S;
+        ADX_HIP(copy2d(x, C, 0, x_cat[0], x_stages[0].in + x_stages[0].hidden, R, C, s));
+        ADX_TRY(run_stages(x_stages, x_cat, R, HX, P("position_embedding"), s));
+        // SiLU(t_emb + state_emb): the only use of the conditioning sum is through SiLU (adaLN inputs)
+        ADX_HIP(add_vec_act(SE, te, SIL, R, d, rows_per_vec, ACT_SILU, s));
+        if (!mm) {
+            const int dh = d / H;
+            for (int i = 0; i < NL; ++i) {
+                const std::string p = "blocks." + std::to_string(i);
+                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation.1.weight", 0, 6 * d, d, p + ".adaLN_modulation.1.bias", MOD, 6 * d, R), s));
+                ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 0, R, s));
+                // post-norm ReLU encoder layer on HN
+                ADX_HIP(linear(lin(HN, d, p + ".attn.self_attn.in_proj_weight", 0, 3 * d, d, p + ".attn.self_attn.in_proj_bias", QB, 3 * d, R), s));
+                AttentionArgs at;
+                at.Q = QB; at.K = QB + d; at.V = QB + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
+                at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)S * 3 * d;
+                at.O = ATT; at.ldo = d; at.o_batch_stride = (int64_t)S * d;
+                at.B = B; at.H = H; at.Sq = S; at.Skv = S; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
+                ADX_HIP(attention(at, s));
+                LinearArgs o = lin(ATT, d, p + ".attn.self_attn.out_proj.weight", 0, d, d, p + ".attn.self_attn.out_proj.bias", Z0, d, R);
+                o.res = HN; o.ldr = d;
+                ADX_HIP(linear(o, s));
+                ADX_TRY(ln_affine(Z0, Z1, p + ".attn.norm1", R, nullptr, 0, nullptr, s));
+                ADX_HIP(linear(lin(Z1, d, p + ".attn.linear1.weight", 0, 4 * d, d, p + ".attn.linear1.bias", FF, 4 * d, R, ACT_RELU), s));
+                LinearArgs f2 = lin(FF, 4 * d, p + ".attn.linear2.weight", 0, d, 4 * d, p + ".attn.linear2.bias", Z0, d, R);
+                f2.res = Z1; f2.ldr = d;
+                ADX_HIP(linear(f2, s));
+                // x = x + gate_msa * norm2(...)
+                ADX_TRY(ln_affine(Z0, HX, p + ".attn.norm2", R, MOD + 2 * d, 6 * d, HX, s));
+                // x = x + gate_mlp * gelu(W2 gelu(W1 modulate(LN(x))))
+                ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 3, R, s));
+                ADX_HIP(linear(lin(HN, d, p + ".mlp.0.weight", 0, 4 * d, d, p + ".mlp.0.bias", FF, 4 * d, R, ACT_GELU_TANH), s));
+                LinearArgs m2 = lin(FF, 4 * d, p + ".mlp.2.weight", 0, d, 4 * d, p + ".mlp.2.bias", HX, d, R, ACT_GELU_TANH);
+                m2.gate = MOD + 5 * d; m2.ldg = 6 * d; m2.res = HX; m2.ldr = d;
+                ADX_HIP(linear(m2, s));
+            }
+        } else {
+            const int kd = d;                   // k_dim = v_dim = d_model per head, per stream
+            const int hd = 2 * kd;              // joint head width (x part then c part)
+            ADX_HIP(copy2d(SE, d, 0, CC, d, R, d, s));
+            for (int i = 0; i < NL; ++i) {
+                const std::string p = "blocks." + std::to_string(i);
+                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation_x.1.weight", 0, 6 * d, d, p + ".adaLN_modulation_x.1.bias", MOD, 6 * d, R), s));
+                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation_c.1.weight", 0, 6 * d, d, p + ".adaLN_modulation_c.1.bias", MODC, 6 * d, R), s));
+                ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 0, R, s));
+                ADX_TRY(ln_mod(CC, HN2, MODC, 6 * d, 0, R, s));
+                const char* names[3] = {"Wq_", "Wk_", "Wv_"};
+                float* dst[3] = {QB, KB, VB};
+                for (int w = 0; w < 3; ++w)
+                    for (int st = 0; st < 2; ++st) {
+                        const std::string wn = p + ".attn." + names[w] + (st ? "c" : "x") + ".weight";
+                        LinearArgs a = lin(st ? HN2 : HN, d, wn, 0, kd * H, d, "", dst[w], (int64_t)hd * H, R);
+                        a.col_group = kd; a.col_stride = hd; a.col_off = st * kd;
+                        ADX_HIP(linear(a, s));
+                    }
+                AttentionArgs at;
+                at.Q = QB; at.K = KB; at.V = VB; at.ldq = at.ldk = at.ldv = (int64_t)hd * H;
+                at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)S * hd * H;
+                at.O = ATT; at.ldo = (int64_t)hd * H; at.o_batch_stride = (int64_t)S * hd * H;
+                at.B = B; at.H = H; at.Sq = S; at.Skv = S; at.dh = hd; at.dv = hd; at.scale = 1.0f / sqrtf((float)kd); at.mask_off = -1;
+                ADX_HIP(attention(at, s));
+                ADX_HIP(linear(lin(ATT, (int64_t)hd * H, p + ".attn.proj.weight", 0, d, hd * H, p + ".attn.proj.bias", OB, d, R), s));
+                for (int st = 0; st < 2; ++st) {
+                    const std::string q = st ? "c" : "x";
+                    float* stream_buf = st ? CC : HX;
+                    float* attn_buf = st ? CA : XA;
+                    const float* mod = st ? MODC : MOD;
+                    float* hn = st ? HN2 : HN;
+                    LinearArgs l1 = lin(OB, d, p + ".linear_" + q + ".0.weight", 0, d, d, p + ".linear_" + q + ".0.bias", attn_buf, d, R, ACT_GELU_TANH);
+                    l1.gate = mod + 2 * d; l1.ldg = 6 * d; l1.res = stream_buf; l1.ldr = d;
+                    ADX_HIP(linear(l1, s));
+                    ADX_TRY(ln_mod(attn_buf, hn, mod, 6 * d, 3, R, s));
+                    ADX_HIP(linear(lin(hn, d, p + ".mlp_" + q + ".0.weight", 0, 4 * d, d, p + ".mlp_" + q + ".0.bias", FF, 4 * d, R, ACT_GELU_TANH), s));
+                    // residual from the stream's block INPUT, not from attn_buf
+                    LinearArgs m2 = lin(FF, 4 * d, p + ".mlp_" + q + ".2.weight", 0, d, 4 * d, p + ".mlp_" + q + ".2.bias", stream_buf, d, R, ACT_GELU_TANH);
+                    m2.gate = mod + 5 * d; m2.ldg = 6 * d; m2.res = stream_buf; m2.ldr = d;
+                    ADX_HIP(linear(m2, s));
+                }
+            }
+        }
+        // final layer
+        ADX_HIP(linear(lin(SIL, d, "final_layer.adaLN_modulation.1.weight", 0, 2 * d, d, "final_layer.adaLN_modulation.1.bias", MODF, 2 * d, R), s));
+        ADX_TRY(ln_mod(HX, HN, MODF, 2 * d, 0, R, s));
+        ADX_HIP(linear(lin(HN, d, "final_layer.linear.weight", 0, C, d, "final_layer.linear.bias", out, C, R), s));
+        return ADX_OK;
+    }
+
+    int check_ready(int B, const char* who) {
+        if (!finalized) { set_error(std::string(who) + ": engine is not finalized"); return ADX_ESTATE; }
+        if (B <= 0) { set_error(std::string(who) + ": batch must be positive"); return ADX_EINVAL; }
+        ADX_HIP(hipSetDevice(device));
+        ADX_TRY(reserve(B));
+        return ADX_OK;
+    }
+
+    int denoise(int B, const float* x, const int64_t* t, const float* state, float* out, hipStream_t s) {
+        ADX_TRY(check_ready(B, "denoise_dit"));
+        ADX_TRY(encode_state(B, state, s));
+        ADX_TRY(time_encoder(t, B, TEB, TEH1, TEH2, s));
+        return run_net(B, x, TEB, S, out, s);
+    }
+
+    int sample(int B, const float* state, const float* noise, int n_noise, float* out, unsigned flags, hipStream_t s) {
+        ADX_TRY(check_ready(B, "sample_dit"));
+        if (steps.empty()) { set_error("sample_dit: no schedule set"); return ADX_ESTATE; }
+        if (cfg.in_dim != cfg.out_dim) { set_error("sample_dit: in_dim must equal out_dim"); return ADX_EINVAL; }
+        const int64_t n = (int64_t)B * S * C;
+        for (const adx_step_coef& k : steps)
+            if (k.c3 != 0.f && k.z_index >= 0 && (!noise || 1 + (int)k.z_index >= n_noise)) {
+                set_error("sample_dit: schedule draws more noise tensors than were supplied"); return ADX_EINVAL;
+            }
+        char key[256];
+        snprintf(key, sizeof key, "d|%d|%p|%p|%d|%p|%u|%d", B, (const void*)state, (const void*)noise, n_noise, (void*)out, flags,
+                 schedule_version);
+        return run(key, flags, s, [&](hipStream_t cs) -> int {
+            ADX_TRY(encode_state(B, state, cs));
+            float* xc = XS0; float* xn = XS1;
+            if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, cs));
+            else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, cs));
+            for (size_t k = 0; k < steps.size(); ++k) {
+                ADX_TRY(run_net(B, xc, temb_table + k * d, 0, MOUT, cs));
+                const int zi = (int)steps[k].z_index;
+                const float* z = (zi >= 0 && steps[k].c3 != 0.f) ? noise + (int64_t)(1 + zi) * n : nullptr;
+                ADX_HIP(sched_step(xc, MOUT, z, xn, nullptr, n, steps_dev + k, cs));
+                std::swap(xc, xn);
+            }
+            if (flags & ADX_FLAG_NORMALIZE) ADX_HIP(denormalize_traj(xc, nullptr, out, n / C, C, cs));
+            else ADX_HIP(copy2d(xc, n, 0, out, n, 1, (int)n, cs));
+            return ADX_OK;
+        });
+    }
+};
+
+}  // namespace
+
+adx_engine* make_engine_dit(const adx_model_config& cfg) {
+    if (cfg.n_inner <= 0 || cfg.connect_dim <= 0) { set_error("engine_create: DiT needs n_inner and connect_dim"); return nullptr; }
+    if (cfg.in_dim != 4 && cfg.in_dim != 2) { set_error("engine_create: DiT in_dim must be 4 or 2"); return nullptr; }
+    const int hd = cfg.variant == ADX_VARIANT_MMDIT ? 2 * cfg.d_model : cfg.d_model / cfg.n_head;
+    (void)hd;
+    return new EngineDiT(cfg);
+}
+
+#define ADX_API extern "C" __attribute__((visibility("default")))
+
+static EngineDiT* as_dit(adx_engine* e, const char* who) {
+    if (!e || (e->cfg.variant != ADX_VARIANT_DIT && e->cfg.variant != ADX_VARIANT_MMDIT)) {
+        set_error(std::string(who) + ": not a DiT engine");
+        return nullptr;
+    }
+    return static_cast<EngineDiT*>(e);
+}
+
+ADX_API int adx_denoise_dit(adx_engine* e, int B, const float* x, const int64_t* t, const float* state, float* out, void* stream) {
+    EngineDiT* a = as_dit(e, "denoise_dit");
+    if (!a) return ADX_EINVAL;
+    if (!x || !t || !state || !out) { set_error("denoise_dit: null pointer"); return ADX_EINVAL; }
+    return a->denoise(B, x, t, state, out, (hipStream_t)stream);
+}
+
+ADX_API int adx_sample_dit(adx_engine* e, int B, const float* state, const float* noise, int n_noise, float* out, unsigned flags,
+                           void* stream) {
+    EngineDiT* a = as_dit(e, "sample_dit");
+    if (!a) return ADX_EINVAL;
+    if (!state || !out) { set_error("sample_dit: null pointer"); return ADX_EINVAL; }
+    if (!noise && !(flags & ADX_FLAG_INIT_ZERO)) { set_error("sample_dit: noise is required unless ADX_FLAG_INIT_ZERO"); return ADX_EINVAL; }
+    return a->sample(B, state, noise, n_noise, out, flags, (hipStream_t)stream);
+}

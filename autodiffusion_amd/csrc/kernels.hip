@@ -1,0 +1,610 @@
+// HIP kernels for the trajectory-diffusion sampling path, written for gfx950 (CDNA4):
+// 64-lane wavefronts, MFMA matrix instructions, LDS-staged tiles.
+#include "adx_ops.h"
+
+#include <math.h>
+
+namespace adx {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case ACT_GELU_TANH: {
+            float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+            return 0.5f * v * (1.f + tanhf(u));
+        }
+        case ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        case ACT_SILU: return v / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ int64_t map_row(const RowMap& r, int m) {
+    if (r.per_batch == 0) return m;
+    return (int64_t)(m / r.per_batch) * r.batch_stride + (m % r.per_batch) + r.off;
+}
+
+// ============================================================================================
+// Linear: Y = res + gate * act(X W^T + bias + pos).  64x64 output tile per 256-thread workgroup,
+// K staged through LDS in steps of 32; each of the 4 waves owns a 32x32 sub-tile as 2x2 MFMA tiles.
+//   PREC_F32 : v_mfma_f32_16x16x4_f32 (exact f32 products and sums, k-ordered fma chain)
+//   PREC_BF16: v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 while staged, f32 accumulate)
+// A row's result depends only on that row of X (no split-K, no atomics), so outputs are
+// identical however the batch is sharded over GPUs.
+// ============================================================================================
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int LDS_F32 = BK + 4;   // floats per LDS row (144 B: keeps 16-B alignment, staggers banks)
+constexpr int LDS_BF = BK + 8;    // bf16 per LDS row (80 B)
+
+template <int PREC>
+__global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32 * 4];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + BM * LDS_F32;
+    unsigned short* Ab = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* Bb = Ab + BM * LDS_BF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int M = a.M, N = a.N, K = a.K;
+
+    // ---- staging assignments
+    const int ar = tid >> 3, akq = (tid & 7) * 4;          // A (and f32 W): rows ar, ar+32; 4 k's
+    const float* arow[2];
+    bool arow_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + ar + 32 * i;
+        arow_ok[i] = m < M;
+        arow[i] = a.X + map_row(a.xmap, arow_ok[i] ? m : 0) * a.ldx;
+    }
+    const bool xvec = ((K & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+    const float* Wf = reinterpret_cast<const float*>(a.W);
+    const unsigned short* Wb = reinterpret_cast<const unsigned short*>(a.W);
+    const bool wvec_f = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
+    const bool wvec_b = ((K & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
+    const int br = tid >> 2, bk8 = (tid & 3) * 8;            // bf16 W: row br, 8 k's
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        // ---- stage X tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int k = k0 + akq;
+            if (arow_ok[i]) {
+                if (xvec && k + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(arow[i] + k);
+                } else {
+                    if (k < K) v.x = arow[i][k];
+                    if (k + 1 < K) v.y = arow[i][k + 1];
+                    if (k + 2 < K) v.z = arow[i][k + 2];
+                    if (k + 3 < K) v.w = arow[i][k + 3];
+                }
+                if (a.in_act != ACT_NONE) {
+                    v.x = apply_act(v.x, a.in_act); v.y = apply_act(v.y, a.in_act);
+                    v.z = apply_act(v.z, a.in_act); v.w = apply_act(v.w, a.in_act);
+                }
+            }
+            const int r = ar + 32 * i;
+            if (PREC == PREC_F32) {
+                *reinterpret_cast<float4*>(&As[r * LDS_F32 + akq]) = v;
+            } else {
+                ushort4 p = make_ushort4(f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w));
+                *reinterpret_cast<ushort4*>(&Ab[r * LDS_BF + akq]) = p;
+            }
+        }
+        // ---- stage W tile
+        if (PREC == PREC_F32) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = ar + 32 * i, n = n0 + r, k = k0 + akq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < N) {
+                    const float* w = Wf + (int64_t)n * K;
+                    if (wvec_f && k + 3 < K) {
+                        v = *reinterpret_cast<const float4*>(w + k);
+                    } else {
+                        if (k < K) v.x = w[k];
+                        if (k + 1 < K) v.y = w[k + 1];
+                        if (k + 2 < K) v.z = w[k + 2];
+                        if (k + 3 < K) v.w = w[k + 3];
+                    }
+                }
+                *reinterpret_cast<float4*>(&Bs[r * LDS_F32 + akq]) = v;
+            }
+        } else {
+            const int n = n0 + br, k = k0 + bk8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n < N) {
+                const unsigned short* w = Wb + (int64_t)n * K;
+                if (wvec_b && k + 7 < K) {
+                    v = *reinterpret_cast<const uint4*>(w + k);
+                } else {
+                    unsigned short e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = (k + j < K) ? w[k + j] : (unsigned short)0;
+                    v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+                    v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+                }
+            }
+            *reinterpret_cast<uint4*>(&Bb[br * LDS_BF + bk8]) = v;
+        }
+        __syncthreads();
+        // ---- MFMA over the staged K step
+        if (PREC == PREC_F32) {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 16) {
+                float4 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const float4*>(&As[(wr * 32 + i * 16 + (lane & 15)) * LDS_F32 + kk + 4 * (lane >> 4)]);
+                    bfr[i] = *reinterpret_cast<const float4*>(&Bs[(wc * 32 + i * 16 + (lane & 15)) * LDS_F32 + kk + 4 * (lane >> 4)]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bfr[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bfr[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bfr[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bfr[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(&Ab[(wr * 32 + i * 16 + (lane & 15)) * LDS_BF + 8 * (lane >> 4)]);
+                bfr[i] = *reinterpret_cast<const bf16x8*>(&Bb[(wc * 32 + i * 16 + (lane & 15)) * LDS_BF + 8 * (lane >> 4)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
+            if (m >= M) continue;
+            const int64_t yrow = map_row(a.ymap, m);
+            const float* posrow = a.pos ? a.pos + (int64_t)((m % a.pos_period) + a.pos_off) * a.ldp : nullptr;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wc * 32 + j * 16 + (lane & 15);
+                if (n >= N) continue;
+                float v = acc[i][j][r];
+                if (a.bias) v += a.bias[n];
+                if (posrow) v += posrow[n];
+                v = apply_act(v, a.act);
+                if (a.gate) v *= a.gate[yrow * a.ldg + n];
+                if (a.res) v += a.res[yrow * a.ldr + n];
+                const int nc = a.col_group ? (n / a.col_group) * a.col_stride + (n % a.col_group) + a.col_off : n;
+                a.Y[yrow * a.ldy + nc] = v;
+            }
+        }
+    }
+}
+
+hipError_t linear(const LinearArgs& a, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
+    if (a.prec == PREC_BF16)
+        hipLaunchKernelGGL(linear_kernel<PREC_BF16>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(linear_kernel<PREC_F32>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ============================================================================================
+// LayerNorm (+affine, +adaLN modulate, +ReLU): one wavefront per row, centred two-pass variance.
+// ============================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* x = a.x + map_row(a.xmap, row) * a.ldx;
+    float* y = a.y + map_row(a.ymap, row) * a.ldy;
+    const int d = a.d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += x[c];
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int c = lane; c < d; c += 64) { float t = x[c] - mean; q += t * t; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + a.eps);
+    const float* sh = a.shift ? a.shift + (int64_t)row * a.ldm : nullptr;
+    const float* sc = a.scale ? a.scale + (int64_t)row * a.ldm : nullptr;
+    for (int c = lane; c < d; c += 64) {
+        float v = (x[c] - mean) * rstd;
+        if (a.gamma) v = v * a.gamma[c] + a.beta[c];
+        if (sc) v = v * (1.f + sc[c]) + sh[c];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (a.gate) v *= a.gate[(int64_t)row * a.ldg + c];
+        if (a.res) v += a.res[(int64_t)row * a.ldr + c];
+        y[c] = v;
+    }
+}
+
+hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
+    if (a.rows <= 0 || a.d <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ============================================================================================
+// Attention, small head dimension (<= 16): one thread per query row, keys/values streamed through
+// LDS in tiles of 256 and read as broadcasts; online softmax in registers, blocks of 8 keys.
+// ============================================================================================
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_small_kernel(const AttentionArgs a) {
+    constexpr int KT = 256;
+    __shared__ __attribute__((aligned(16))) float Ks[KT * DH];
+    __shared__ __attribute__((aligned(16))) float Vs[KT * DH];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool qok = q < a.Sq;
+    float qv[DH], o[DH];
+    const float* Qp = a.Q + (int64_t)b * a.q_batch_stride + (int64_t)(qok ? q : 0) * a.ldq + h * DH;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) { qv[c] = Qp[c] * (a.scale * LOG2E); o[c] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const int jmax = a.mask_off >= 0 ? q + a.mask_off : a.Skv - 1;   // last visible key of this query
+
+    for (int j0 = 0; j0 < a.Skv; j0 += KT) {
+        const int nk = min(KT, a.Skv - j0);
+        __syncthreads();
+        if ((int)threadIdx.x < nk) {
+            const float* Kp = a.K + (int64_t)b * a.k_batch_stride + (int64_t)(j0 + threadIdx.x) * a.ldk + h * DH;
+            const float* Vp = a.V + (int64_t)b * a.v_batch_stride + (int64_t)(j0 + threadIdx.x) * a.ldv + h * DH;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) { Ks[threadIdx.x * DH + c] = Kp[c]; Vs[threadIdx.x * DH + c] = Vp[c]; }
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nk; jj += 8) {
+            float s[8];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jj + u;
+                float d = 0.f;
+                if (j < nk) {
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) d = fmaf(qv[c], Ks[j * DH + c], d);
+                }
+                s[u] = (j < nk && j0 + j <= jmax) ? d : -INFINITY;
+                mx = fmaxf(mx, s[u]);
+            }
+            const float mn = fmaxf(m, mx);
+            if (mn == -INFINITY) continue;
+            const float alpha = exp2f(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) o[c] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = min(jj + u, nk - 1);
+                const float p = exp2f(s[u] - mn);
+                l += p;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) o[c] = fmaf(p, Vs[j * DH + c], o[c]);
+            }
+            m = mn;
+        }
+    }
+    if (qok) {
+        float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + h * DH;
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) Op[c] = o[c] * inv;
+    }
+}
+
+// ============================================================================================
+// Attention, general head dimension: one workgroup per (batch, head, 16 queries); scores of the
+// 16 queries against every key live in LDS, the head dimension is streamed in chunks of 64.
+// ============================================================================================
+constexpr int QT = 16, DC = 64, KC = 64;
+
+__global__ __launch_bounds__(256) void attn_general_kernel(const AttentionArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* S = dyn;                                // [QT][Skv]
+    float* Qc = S + QT * a.Skv;                    // [QT][DC]
+    float* Kc = Qc + QT * DC;                      // [KC][DC + 1]   (also the V tile [KC][DC])
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QT;
+    const int tid = threadIdx.x;
+    const int tq = tid >> 4, tl = tid & 15;
+    const int Skv = a.Skv;
+    const float* Qb = a.Q + (int64_t)b * a.q_batch_stride + h * a.dh;
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + h * a.dh;
+    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + h * a.dv;
+
+    // ---- scores
+    for (int j0 = 0; j0 < Skv; j0 += KC) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < a.dh; c0 += DC) {
+            const int nc = min(DC, a.dh - c0);
+            __syncthreads();
+            for (int i = tid; i < QT * DC; i += 256) {
+                const int r = i / DC, c = i % DC;
+                Qc[i] = (q0 + r < a.Sq && c < nc) ? Qb[(int64_t)(q0 + r) * a.ldq + c0 + c] : 0.f;
+            }
+            for (int i = tid; i < KC * DC; i += 256) {
+                const int r = i / DC, c = i % DC;
+                Kc[r * (DC + 1) + c] = (j0 + r < Skv && c < nc) ? Kb[(int64_t)(j0 + r) * a.ldk + c0 + c] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* kr = &Kc[(tl + 16 * u) * (DC + 1)];
+                const float* qr = &Qc[tq * DC];
+                float d = acc[u];
+                for (int c = 0; c < DC; ++c) d = fmaf(qr[c], kr[c], d);
+                acc[u] = d;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + tl + 16 * u;
+            if (j < Skv) {
+                const bool vis = a.mask_off < 0 || j <= q0 + tq + a.mask_off;
+                S[tq * Skv + j] = vis ? acc[u] * a.scale : -INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax over each query row: 16 lanes per row
+    {
+        float* row = &S[tq * Skv];
+        float mx = -INFINITY;
+        for (int j = tl; j < Skv; j += 16) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        float sum = 0.f;
+        for (int j = tl; j < Skv; j += 16) { float p = exp2f((row[j] - mx) * LOG2E); row[j] = p; sum += p; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        const float inv = 1.f / sum;
+        for (int j = tl; j < Skv; j += 16) row[j] *= inv;
+    }
+    // ---- P V, value dimension in chunks of 64: thread (tq, tl) owns 4 consecutive output dims
+    for (int c0 = 0; c0 < a.dv; c0 += DC) {
+        const int nc = min(DC, a.dv - c0);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < Skv; j0 += KC) {
+            const int nk = min(KC, Skv - j0);
+            __syncthreads();
+            for (int i = tid; i < KC * DC; i += 256) {
+                const int r = i / DC, c = i % DC;
+                Kc[i] = (r < nk && c < nc) ? Vb[(int64_t)(j0 + r) * a.ldv + c0 + c] : 0.f;
+            }
+            __syncthreads();
+            const float* prow = &S[tq * Skv + j0];
+            for (int j = 0; j < nk; ++j) {
+                const float p = prow[j];
+                const float4 v = *reinterpret_cast<const float4*>(&Kc[j * DC + tl * 4]);
+                acc[0] = fmaf(p, v.x, acc[0]); acc[1] = fmaf(p, v.y, acc[1]);
+                acc[2] = fmaf(p, v.z, acc[2]); acc[3] = fmaf(p, v.w, acc[3]);
+            }
+        }
+        if (q0 + tq < a.Sq) {
+            float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)(q0 + tq) * a.ldo + h * a.dv + c0 + tl * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (tl * 4 + u < nc) Op[u] = acc[u];
+        }
+    }
+}
+
+hipError_t attention(const AttentionArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.H <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.dh <= 0 || a.dv <= 0) return hipErrorInvalidValue;
+    if (a.dh == a.dv && (a.dh == 4 || a.dh == 8 || a.dh == 16)) {
+        dim3 grid((a.Sq + 255) / 256, a.H, a.B);
+        if (a.dh == 4) hipLaunchKernelGGL(attn_small_kernel<4>, grid, dim3(256), 0, stream, a);
+        else if (a.dh == 8) hipLaunchKernelGGL(attn_small_kernel<8>, grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(attn_small_kernel<16>, grid, dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+    const size_t smem = sizeof(float) * ((size_t)QT * a.Skv + QT * DC + KC * (DC + 1));
+    if (smem > 64 * 1024) return hipErrorInvalidValue;   // Skv <= ~880 for the general kernel
+    dim3 grid((a.Sq + QT - 1) / QT, a.H, a.B);
+    hipLaunchKernelGGL(attn_general_kernel, grid, dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+// ============================================================================================
+// Small elementwise kernels
+// ============================================================================================
+__global__ void timestep_embedding_kernel(const int64_t* t, int n, int dim, float* out, int64_t ldo) {
+    const int i = blockIdx.x;
+    const int half = dim / 2;
+    const float tv = (float)t[i];
+    const float step = -(logf(10000.0f) / (float)(half - 1));
+    for (int c = threadIdx.x; c < half; c += blockDim.x) {
+        const float w = expf((float)c * step);
+        const float arg = tv * w;
+        out[i * ldo + c] = sinf(arg);
+        out[i * ldo + half + c] = cosf(arg);
+    }
+}
+
+hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream) {
+    if (n <= 0 || dim < 4 || (dim & 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(n), dim3(64), 0, stream, t, n, dim, out, ldo);
+    return hipGetLastError();
+}
+
+__global__ void add_vec_act_kernel(const float* x, const float* vec, float* y, int64_t total, int cols,
+                                   int64_t rows_per_vec, int act) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        float v = x[i];
+        if (vec) {
+            const int64_t r = i / cols;
+            const int c = (int)(i % cols);
+            v += vec[(rows_per_vec > 0 ? (r / rows_per_vec) * cols : 0) + c];
+        }
+        y[i] = apply_act(v, act);
+    }
+}
+
+static inline int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+hipError_t add_vec_act(const float* x, const float* vec, float* y, int64_t rows, int cols, int64_t rows_per_vec, int act,
+                       hipStream_t stream) {
+    const int64_t total = rows * cols;
+    if (total <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_vec_act_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, vec, y, total, cols, rows_per_vec, act);
+    return hipGetLastError();
+}
+
+__global__ void set_row_kernel(float* out, int64_t batch_stride, int B, const float* a, int64_t a_stride, const float* bvec,
+                               int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * cols) return;
+    const int b = i / cols, c = i % cols;
+    out[(int64_t)b * batch_stride + c] = a[(int64_t)b * a_stride + c] + (bvec ? bvec[c] : 0.f);
+}
+
+hipError_t set_row(float* out, int64_t batch_stride, int B, const float* a, int64_t a_stride, const float* bvec, int cols,
+                   hipStream_t stream) {
+    if (B <= 0 || cols <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(set_row_kernel, dim3((B * cols + 255) / 256), dim3(256), 0, stream, out, batch_stride, B, a, a_stride, bvec, cols);
+    return hipGetLastError();
+}
+
+__global__ void normalize_kernel(const float* x, float* y, int64_t total, int C) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const float v = x[i];
+    y[i] = c == 0 ? v / 25.f - 1.0f : (c == 1 ? v / 5.f : v);
+}
+
+hipError_t normalize_traj(const float* x, float* y, int64_t n_points, int C, hipStream_t stream) {
+    const int64_t total = n_points * C;
+    if (total <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, total, C);
+    return hipGetLastError();
+}
+
+__global__ void denormalize_kernel(const float* y, const float* residual, float* x, int64_t total, int C) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const float v = y[i];
+    float r = c == 0 ? (v + 1.0f) * 25.f : (c == 1 ? v * 5.f : (c == 2 ? 0.f : v));
+    if (residual) r += residual[i];
+    x[i] = r;
+}
+
+hipError_t denormalize_traj(const float* y, const float* residual, float* x, int64_t n_points, int C, hipStream_t stream) {
+    const int64_t total = n_points * C;
+    if (total <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(denormalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, residual, x, total, C);
+    return hipGetLastError();
+}
+
+__global__ void affine_channels_kernel(const float* x, const float* mean, const float* std, float* y, int64_t total, int C) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    y[i] = x[i] * std[c] + mean[c];
+}
+
+hipError_t affine_channels(const float* x, const float* mean, const float* std, float* y, int64_t n_points, int C,
+                           hipStream_t stream) {
+    const int64_t total = n_points * C;
+    if (total <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(affine_channels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, mean, std, y, total, C);
+    return hipGetLastError();
+}
+
+// Scheduler update: 16 B per element in, 4 B out, ~10 flops -- pure HBM streaming.
+__global__ void sched_step_kernel(const float* x, const float* out, const float* z, float* xn, float* x0_out,
+                                  int64_t n, const StepCoef* coef) {
+    const StepCoef k = *coef;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float xv = x[i], ov = out[i];
+        float x0 = k.a0 * xv + k.a1 * ov;
+        x0 = fminf(fmaxf(x0, -k.clip), k.clip);
+        const float eps = k.eps_mode != 0.f ? (k.b0 * xv - x0) * k.b1 : ov;
+        float r = k.c0 * x0 + k.c1 * xv + k.c2 * eps;
+        if (k.c3 != 0.f) r += k.c3 * z[i];
+        xn[i] = r;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+hipError_t sched_step(const float* x, const float* model_out, const float* z, float* x_next, float* x0_out,
+                      int64_t n, const StepCoef* coef_dev, hipStream_t stream) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sched_step_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, model_out, z, x_next, x0_out, n, coef_dev);
+    return hipGetLastError();
+}
+
+__global__ void to_bf16_kernel(const float* x, uint16_t* y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = f2bf(x[i]);
+}
+
+hipError_t to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+    return hipGetLastError();
+}
+
+__global__ void copy2d_kernel(const float* src, int64_t lds, int64_t src_rows, float* dst, int64_t ldd, int64_t rows, int cols) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, total = rows * cols;
+    for (; i < total; i += stride) {
+        const int64_t r = i / cols; const int c = (int)(i % cols);
+        dst[r * ldd + c] = src[(src_rows > 0 ? r % src_rows : r) * lds + c];
+    }
+}
+
+hipError_t copy2d(const float* src, int64_t lds, int64_t src_rows, float* dst, int64_t ldd, int64_t rows, int cols,
+                  hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, stream, src, lds, src_rows, dst, ldd, rows, cols);
+    return hipGetLastError();
+}
+
+}  // namespace adx

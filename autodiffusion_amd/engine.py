@@ -1,0 +1,121 @@
+"""Python handle around an ``adx_engine`` (weights + workspace + sampling loop on the GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ModelConfig, StepCoef, check, current_stream, f32c, ptr
+
+
+class Engine:
+    """Owns one ``adx_engine``.  Parameters are pushed by name; the handle is freed on ``close``/GC."""
+
+    def __init__(self, **cfg):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.AdxError("no GPU visible: the sampling engines run on an MI355X only")
+        self.cfg = ModelConfig(**cfg)
+        h = C.c_void_p()
+        check(self.lib.adx_engine_create(C.byref(self.cfg), C.byref(h)), "adx_engine_create")
+        self.h = h
+        self._rows = None
+        self._stamp = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.adx_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def load(self, named: Iterable[Tuple[str, torch.Tensor]]):
+        torch.cuda.synchronize()
+        for name, t in named:
+            t = f32c(t)
+            if not t.is_cuda:
+                t = t.cuda()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(self.lib.adx_engine_set_tensor(self.h, name.encode(), ptr(t), shape, t.dim()), f"set_tensor({name})")
+        check(self.lib.adx_engine_finalize(self.h), "adx_engine_finalize")
+        self._rows = None  # set_tensor invalidates nothing on the schedule, but keep the cache honest
+
+    def sync_from(self, module: torch.nn.Module, prefix: str = ""):
+        """(Re)load the parameters of ``module`` if any changed since the last call."""
+        params = [(n, p) for n, p in module.named_parameters()]
+        stamp = tuple((n, p.data_ptr(), p._version, str(p.device)) for n, p in params)
+        if stamp != self._stamp:
+            self.load((n[len(prefix):] if n.startswith(prefix) else n, p) for n, p in params)
+            self._stamp = stamp
+
+    def reserve(self, batch: int):
+        check(self.lib.adx_engine_reserve(self.h, int(batch)), "adx_engine_reserve")
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.adx_engine_workspace_bytes(self.h))
+
+    # ------------------------------------------------------------------ schedule
+    def set_schedule(self, rows: Sequence[Sequence[float]]):
+        key = tuple(tuple(r) for r in rows)
+        if key == self._rows:
+            return
+        arr = (StepCoef * len(rows))()
+        for i, r in enumerate(rows):
+            arr[i] = StepCoef(*[float(v) for v in r])
+        check(self.lib.adx_engine_set_schedule(self.h, arr, len(rows)), "adx_engine_set_schedule")
+        self._rows = key
+
+    # ------------------------------------------------------------------ calls
+    def denoise_a(self, x, t, maps, transition, prior) -> torch.Tensor:
+        B, T = x.shape[0], x.shape[1]
+        x, maps, transition, prior = f32c(x), (f32c(maps) if maps is not None else None), f32c(transition), f32c(prior)
+        t = t.to(torch.int64).contiguous()
+        out = torch.empty(B, T, self.cfg.out_dim, device=x.device, dtype=torch.float32)
+        check(self.lib.adx_denoise_a(self.h, B, ptr(x), ptr(t), ptr(maps), ptr(transition), ptr(prior), ptr(out), current_stream()),
+              "adx_denoise_a")
+        return out
+
+    def denoise_dit(self, x, t, state) -> torch.Tensor:
+        B = x.shape[0]
+        x, state = f32c(x), f32c(state)
+        t = t.to(torch.int64).contiguous()
+        out = torch.empty_like(x)
+        check(self.lib.adx_denoise_dit(self.h, B, ptr(x), ptr(t), ptr(state), ptr(out), current_stream()), "adx_denoise_dit")
+        return out
+
+    def sample_a(self, maps, transition, prior, noise, flags: int, out: Optional[torch.Tensor] = None, trace: bool = False):
+        B = transition.shape[0]
+        T, Cin = self.cfg.horizon, self.cfg.in_dim
+        n_noise = 0 if noise is None else noise.shape[0]
+        if out is None:
+            out = torch.empty(B, T, Cin, device=transition.device, dtype=torch.float32)
+        n_steps = len(self._rows)
+        tx = torch.empty(n_steps, B, T, Cin, device=out.device) if trace else None
+        to = torch.empty(n_steps, B, T, Cin, device=out.device) if trace else None
+        check(self.lib.adx_sample_a(self.h, B, ptr(maps), ptr(transition), ptr(prior), ptr(noise), n_noise, ptr(out), ptr(tx), ptr(to),
+                                    flags, current_stream()), "adx_sample_a")
+        return (out, tx, to) if trace else out
+
+    def generate_a(self, maps, prior_full, init_x, noise, frame_stack: int, flags: int, out: Optional[torch.Tensor] = None):
+        B, S = prior_full.shape[0], prior_full.shape[1]
+        n_noise = 0 if noise is None else noise.shape[1]
+        if out is None:
+            out = torch.empty(B, S, 4, device=prior_full.device, dtype=torch.float32)
+        check(self.lib.adx_generate_a(self.h, B, S, frame_stack, ptr(maps), ptr(prior_full), ptr(init_x), ptr(noise), n_noise, ptr(out),
+                                      flags, current_stream()), "adx_generate_a")
+        return out
+
+    def sample_dit(self, state, noise, flags: int, out: Optional[torch.Tensor] = None):
+        B, S = state.shape[0], state.shape[1]
+        n_noise = 0 if noise is None else noise.shape[0]
+        if out is None:
+            out = torch.empty(B, S, self.cfg.in_dim, device=state.device, dtype=torch.float32)
+        check(self.lib.adx_sample_dit(self.h, B, ptr(state), ptr(noise), n_noise, ptr(out), flags, current_stream()), "adx_sample_dit")
+        return out

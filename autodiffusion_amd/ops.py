@@ -1,0 +1,99 @@
+"""Operator-level wrappers over the C ABI (one HIP kernel launch each).  Device tensors in, device tensors out."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import StepCoef, check, current_stream, f32c, ptr
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    lib = _lib.load()
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty(*t.shape, dim, device=t.device, dtype=torch.float32)
+    check(lib.adx_op_timestep_embedding(ptr(t), t.numel(), dim, ptr(out), current_stream()), "timestep_embedding")
+    return out
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = f32c(x)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.int16)
+    check(lib.adx_op_to_bf16(ptr(x), ptr(y), x.numel(), current_stream()), "to_bf16")
+    return y
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = _lib.ACT_NONE,
+           precision: str = "fp32") -> torch.Tensor:
+    lib = _lib.load()
+    x = f32c(x)
+    K = x.shape[-1]
+    N = w.shape[0]
+    M = x.numel() // K
+    prec = {"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[precision]
+    wd = to_bf16(w) if prec == _lib.PREC_BF16 else f32c(w)
+    b = f32c(bias) if bias is not None else None
+    y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    check(lib.adx_op_linear(ptr(x), ptr(wd), ptr(b), ptr(y), M, N, K, act, prec, current_stream()), "linear")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma=None, beta=None, shift=None, scale=None, eps: float = 1e-5, relu: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    x = f32c(x)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    ld_mod = 0
+    if shift is not None:
+        shift, scale = f32c(shift), f32c(scale)
+        ld_mod = d
+    y = torch.empty_like(x)
+    check(lib.adx_op_layernorm(ptr(x), ptr(f32c(gamma)) if gamma is not None else None, ptr(f32c(beta)) if beta is not None else None,
+                               ptr(shift), ptr(scale), ld_mod, eps, int(relu), rows, d, ptr(y), current_stream()), "layernorm")
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_head: int, scale: Optional[float] = None,
+              mask_off: int = -1) -> torch.Tensor:
+    """q (B,Sq,H*dh), k (B,Skv,H*dh), v (B,Skv,H*dv) -> (B,Sq,H*dv)."""
+    lib = _lib.load()
+    q, k, v = f32c(q), f32c(k), f32c(v)
+    B, Sq, Skv = q.shape[0], q.shape[1], k.shape[1]
+    dh, dv = q.shape[2] // n_head, v.shape[2] // n_head
+    if scale is None:
+        scale = dh ** -0.5
+    o = torch.empty(B, Sq, n_head * dv, device=q.device, dtype=torch.float32)
+    check(lib.adx_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), B, n_head, Sq, Skv, dh, dv, float(scale), mask_off, current_stream()),
+          "attention")
+    return o
+
+
+def normalize(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = f32c(x)
+    y = torch.empty_like(x)
+    check(lib.adx_op_normalize(ptr(x), ptr(y), x.numel() // x.shape[-1], x.shape[-1], current_stream()), "normalize")
+    return y
+
+
+def denormalize(y: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    y = f32c(y)
+    r = f32c(residual) if residual is not None else None
+    x = torch.empty_like(y)
+    check(lib.adx_op_denormalize(ptr(y), ptr(r), ptr(x), y.numel() // y.shape[-1], y.shape[-1], current_stream()), "denormalize")
+    return x
+
+
+def sched_step(x: torch.Tensor, model_out: torch.Tensor, z: Optional[torch.Tensor], row: Sequence[float], want_x0: bool = False):
+    lib = _lib.load()
+    x, model_out = f32c(x), f32c(model_out)
+    z = f32c(z) if z is not None else None
+    coef = torch.tensor([float(v) for v in row], dtype=torch.float32, device=x.device)
+    xn = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    check(lib.adx_op_sched_step(ptr(x), ptr(model_out), ptr(z), ptr(xn), ptr(x0), x.numel(), ptr(coef), current_stream()), "sched_step")
+    return (xn, x0) if want_x0 else xn

@@ -1,0 +1,323 @@
+"""Drop-in classes for the reference's live refinement path (variant A), backed by libadx.so.
+
+Interfaces mirrored (paths relative to the reference tree):
+
+* ``Transformer``          transformer4planning/models/diffusion_loss/transformer.py:10-273
+* ``DiffusionWrapper``     transformer4planning/models/diffusion_loss/TrajRefiner.py:123-458
+* ``TrajectoryRefiner``    transformer4planning/models/diffusion_loss/TrajRefiner.py:50-121
+* ``DiffusionAugmentation`` (refiner part) transformer4planning/models/backbone/DiffusionAugmentation.py:29-195
+
+Parameter and buffer names are the reference's, so a reference ``state_dict`` loads
+with ``load_state_dict``.  The modules only *hold* parameters; every forward runs in
+the HIP engine.  Sampling (eval mode) is implemented; the training loss is not.
+
+Deviations, all deliberate:
+* ``Transformer.forward`` returns ``(B, T, C)`` always (the reference's trailing
+  ``squeeze()`` drops size-1 axes, transformer.py:273).
+* caller tensors are never modified (the reference normalises ``prior[...]`` in place
+  inside the condition dict, TrajRefiner.py:322-323).
+* every sampling entry point takes an optional ``noise`` tensor so results are
+  reproducible and shard-invariant; without it, noise is drawn with ``torch.randn``.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, schedules
+from .engine import Engine
+
+
+# ------------------------------------------------------------------ parameter holders
+class _Lin(nn.Module):
+    def __init__(self, n_in: int, n_out: int, bias: bool = True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n_out, n_in) * 0.02)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(n_out))
+
+
+class _Norm(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+
+class _MHA(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.randn(3 * d, d) * 0.02)
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _Lin(d, d)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.linear1 = _Lin(d, 4 * d)
+        self.linear2 = _Lin(4 * d, d)
+        self.norm1 = _Norm(d)
+        self.norm2 = _Norm(d)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, d: int):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.multihead_attn = _MHA(d)
+        self.linear1 = _Lin(d, 4 * d)
+        self.linear2 = _Lin(4 * d, d)
+        self.norm1 = _Norm(d)
+        self.norm2 = _Norm(d)
+        self.norm3 = _Norm(d)
+
+
+class _Stack(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+
+
+class SinusoidalPosEmb(nn.Module):
+    """models/diffusion_loss/positional_embedding.py:5-17."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        return ops.timestep_embedding(x, self.dim)
+
+
+class Transformer(nn.Module):
+    """Encoder/decoder denoiser.  Constructor arguments as in the reference; ``precision`` ("fp32" | "bf16")
+    and ``elide`` (skip mask-unobservable work) select the engine build."""
+
+    def __init__(self, input_dim: int, output_dim: int, horizon: int, n_cond_steps: int = None, cond_dim: int = 0,
+                 n_prior_steps: int = 0, prior_dim: int = 0, n_layer: int = 4, n_head: int = 8, n_emb: int = 32,
+                 p_drop_emb: float = 0.1, p_drop_attn: float = 0.1, causal_attn: bool = False, time_as_cond: bool = True,
+                 obs_as_cond: bool = False, n_cond_layers: int = 2, map_cond: bool = True,
+                 precision: str = "fp32", elide: bool = True) -> None:
+        super().__init__()
+        if not time_as_cond or not causal_attn or cond_dim <= 0 or n_cond_layers <= 0:
+            raise NotImplementedError("only the configuration the refiner instantiates is implemented: "
+                                      "time_as_cond=True, causal_attn=True, cond_dim>0, n_cond_layers>0")
+        T = horizon
+        T_cond = 1 + n_prior_steps + horizon + (n_cond_steps if map_cond else 0)
+        self.out_features = output_dim
+        self.input_emb = _Lin(input_dim, n_emb)
+        self.pos_emb = nn.Parameter(torch.randn(1, T, n_emb) * 0.02)
+        self.time_emb = SinusoidalPosEmb(n_emb)
+        self.map_cond = map_cond
+        self.cond_obs_emb = _Lin(cond_dim, n_emb) if map_cond else None
+        self.prior_z_emb = _Lin(prior_dim, n_emb)
+        self.cond_pos_emb = nn.Parameter(torch.randn(1, T_cond, n_emb) * 0.02 if map_cond else torch.zeros(1, T_cond, n_emb))
+        self.encoder = _Stack([_EncoderLayer(n_emb) for _ in range(n_cond_layers)])
+        self.decoder = _Stack([_DecoderLayer(n_emb) for _ in range(n_layer)])
+        i = torch.arange(T)[:, None]
+        mask = torch.zeros(T, T).masked_fill(torch.arange(T)[None, :] > i, float("-inf"))
+        mem = torch.zeros(T, T_cond).masked_fill(torch.arange(T_cond)[None, :] > i + 1, float("-inf"))
+        self.register_buffer("mask", mask)
+        self.register_buffer("memory_mask", mem)
+        self.ln_f = _Norm(n_emb)
+        self.head = _Lin(n_emb, output_dim)
+        self.T, self.T_cond, self.horizon = T, T_cond, horizon
+        self.time_as_cond, self.obs_as_cond, self.encoder_only = True, True, False
+        self._dims = dict(d_model=n_emb, n_head=n_head, n_enc_layers=n_cond_layers, n_layers=n_layer, horizon=horizon,
+                          in_dim=input_dim, out_dim=output_dim, n_prior_tokens=n_prior_steps,
+                          prior_dim=prior_dim, n_maps_token=n_cond_steps or 0, maps_dim=cond_dim, map_cond=int(map_cond))
+        if n_prior_steps != horizon:
+            # the conditioning sequence holds `horizon` transition rows and `n_prior_steps` prior rows; both are
+            # embedded by prior_z_emb, so they must have the same token count in every reference instantiation
+            raise NotImplementedError("n_prior_steps must equal horizon")
+        self.precision = precision
+        self.elide = bool(elide)
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+
+    # engine build/sync
+    def engine(self) -> Engine:
+        key = (self.precision, self.elide)
+        if self._engine is None or self._engine_key != key:
+            prec = {"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[self.precision]
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = Engine(variant=_lib.VARIANT_A, precision=prec, elide=int(self.elide), **self._dims)
+            self._engine_key = key
+        self._engine.sync_from(self)
+        return self._engine
+
+    def forward(self, noisy_x: torch.Tensor, timestep, condition: Dict[str, torch.Tensor], **kwargs) -> torch.Tensor:
+        B = noisy_x.shape[0]
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.long, device=noisy_x.device)
+        elif t.dim() == 0:
+            t = t[None].to(noisy_x.device)
+        if t.shape[0] != B:
+            if t.shape[0] != 1:
+                raise ValueError("timestep must be a scalar or have one entry per batch row")
+            t = t.expand(B)
+        return self.engine().denoise_a(noisy_x, t, condition.get("maps_info") if self.map_cond else None,
+                                       condition["transition_info"], condition["trajectory_prior"])
+
+
+class DiffusionWrapper(nn.Module):
+    """Gaussian-diffusion sampler around a denoiser; registers the reference's buffers under the same names."""
+
+    def __init__(self, model, timesteps=1000, sampling_timesteps=None, objective="pred_noise", beta_schedule="sigmoid",
+                 schedule_fn_kwargs=dict(), ddim_sampling_eta=0., min_snr_loss_weight=True, min_snr_gamma=5,
+                 auto_normalize_data=True, residual=False):
+        super().__init__()
+        self.model = model
+        self.objective = objective
+        self.timesteps = timesteps
+        self.residual = residual
+        assert objective in {"pred_noise", "pred_x0", "pred_v"}, \
+            "objective must be either pred_noise (predict noise) or pred_x0 (predict image start) or pred_v (predict v)"
+        betas = schedules.make_betas(beta_schedule, timesteps)
+        self.num_timesteps = int(betas.shape[0])
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for k, v in schedules.diffusion_buffers(betas).items():
+            self.register_buffer(k, v)
+        ac64 = torch.cumprod(1.0 - betas, dim=0)
+        self.register_buffer("loss_weight", schedules.loss_weight(ac64, objective, min_snr_gamma, min_snr_loss_weight).to(torch.float32))
+        self.auto_normalize_data = bool(auto_normalize_data)
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def _buffers_cpu(self):
+        return {k: getattr(self, k).detach().float().cpu() for k in schedules.BUFFER_NAMES}
+
+    def schedule_rows(self):
+        b = self._buffers_cpu()
+        if self.is_ddim_sampling:
+            return schedules.ddim_rows(b, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
+        return schedules.ddpm_rows(b, self.objective)
+
+    def flags(self) -> int:
+        return (_lib.FLAG_NORMALIZE if self.auto_normalize_data else 0) | (_lib.FLAG_RESIDUAL if self.residual else 0)
+
+    def make_noise(self, shape, device, n_chunks: Optional[int] = None):
+        n = 1 + schedules.n_noise_draws(self.schedule_rows())
+        lead = (n,) if n_chunks is None else (n_chunks, n)
+        return torch.randn(*lead, *shape, device=device, dtype=torch.float32)
+
+    @torch.no_grad()
+    def sample(self, prior: Dict[str, torch.Tensor], trajectory_label: torch.Tensor, return_all_timesteps: bool = False,
+               noise: Optional[torch.Tensor] = None, trace: bool = False):
+        if return_all_timesteps:
+            raise NotImplementedError("return_all_timesteps is not supported; pass trace=True for per-step tensors")
+        eng = self.model.engine()
+        eng.set_schedule(self.schedule_rows())
+        shape = tuple(trajectory_label.shape)
+        dev = prior["trajectory_prior"].device
+        if noise is None:
+            noise = self.make_noise(shape, dev)
+        maps = _lib.f32c(prior["maps_info"]) if self.model.map_cond else None
+        return eng.sample_a(maps, _lib.f32c(prior["transition_info"]), _lib.f32c(prior["trajectory_prior"]),
+                            _lib.f32c(noise), self.flags(), trace=trace)
+
+    def forward(self, prior, trajectory_label, get_inter=False, **kwargs):
+        if self.training:
+            raise NotImplementedError("the training loss (p_losses) is outside the accelerated sampling path; call .eval()")
+        return self.sample(prior, trajectory_label, return_all_timesteps=get_inter, **kwargs)
+
+
+class TrajectoryRefiner(nn.Module):
+    """cfg needs: trajectory_dim, frame_stack, n_maps_token, maps_dim, map_cond, beta_schedule, diffusion_timesteps,
+    objective, ddim, normalize, residual (plus optional sampling_timesteps, precision, elide)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        model = Transformer(
+            input_dim=cfg.trajectory_dim, output_dim=cfg.trajectory_dim, horizon=cfg.frame_stack,
+            n_cond_steps=cfg.n_maps_token, cond_dim=cfg.maps_dim, n_prior_steps=cfg.frame_stack, prior_dim=cfg.trajectory_dim,
+            causal_attn=True, map_cond=cfg.map_cond,
+            precision=getattr(cfg, "precision", "fp32"), elide=getattr(cfg, "elide", True))
+        self.diffusion = DiffusionWrapper(
+            model, beta_schedule=cfg.beta_schedule, timesteps=cfg.diffusion_timesteps, objective=cfg.objective,
+            sampling_timesteps=getattr(cfg, "sampling_timesteps", None),
+            ddim_sampling_eta=cfg.ddim, auto_normalize_data=cfg.normalize, residual=cfg.residual)
+
+    @torch.no_grad()
+    def generate(self, label, transition_info, trajectory_prior, maps_info, noise: Optional[torch.Tensor] = None):
+        condition = {"maps_info": maps_info, "transition_info": transition_info, "trajectory_prior": trajectory_prior}
+        return self.diffusion.sample(condition, label, noise=noise)
+
+    def forward(self, label, transition_info, trajectory_prior, maps_info):
+        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
+
+
+class DiffusionAugmentation(nn.Module):
+    """The refiner half of the reference's DiffusionAugmentation wrapper: chunk loop around TrajectoryRefiner.
+
+    Phase 1 (the frozen STR backbone that yields ``traj_logits`` (B,80,4) and ``maps_info`` (B,788,256)) is not part
+    of this package.  Pass ``str_model`` (any object whose ``generate(**kwargs)`` returns that dict) to get the
+    reference's ``generate(**batch)`` behaviour, or call ``generate(trajectory_prior=..., maps_info=...)`` directly.
+    """
+
+    def __init__(self, config, str_model=None):
+        super().__init__()
+        config.trajectory_dim = 4
+        config.learnable_init_traj = True
+        config.maps_dim = 256
+        config.n_maps_token = 788
+        self.cfg = self.config = config
+        self.trajectory_dim = 4
+        self.frame_stack = config.frame_stack
+        self.map_cond = config.map_cond
+        self.residual = config.residual
+        self.str_model = [str_model]          # kept out of the module tree on purpose
+        self.diffusion = TrajectoryRefiner(config)
+        self.init_x = nn.Parameter(torch.randn(self.frame_stack, self.trajectory_dim))
+
+    @torch.no_grad()
+    def generate(self, noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, **kwargs):
+        if "trajectory_prior" in kwargs and "maps_info" in kwargs:
+            trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
+        else:
+            if self.str_model[0] is None:
+                raise ValueError("generate() needs either trajectory_prior/maps_info or a str_model for phase 1")
+            str_result = self.str_model[0].generate(**kwargs)
+            trajectory_prior, maps_info = str_result["traj_logits"], str_result["maps_info"]
+        B, S = trajectory_prior.shape[:2]
+        if S % self.frame_stack != 0:
+            raise ValueError("Number of frames must be divisible by frame stack size")
+        wrapper = self.diffusion.diffusion
+        eng = wrapper.model.engine()
+        eng.set_schedule(wrapper.schedule_rows())
+        n_chunks = S // self.frame_stack
+        if noise is None:
+            noise = wrapper.make_noise((B, self.frame_stack, self.trajectory_dim), trajectory_prior.device, n_chunks)
+        maps = _lib.f32c(maps_info) if self.map_cond else None
+        traj = eng.generate_a(maps, _lib.f32c(trajectory_prior), _lib.f32c(self.init_x), _lib.f32c(noise), self.frame_stack,
+                              wrapper.flags(), out=out)
+        return {"traj_logits": traj}
+
+    def forward(self, return_dict=None, **kwargs):
+        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path; use generate()")
+
+
+def refiner_config(frame_stack: int = 10, diffusion_timesteps: int = 100, objective: str = "pred_noise",
+                   beta_schedule: str = "cosine", ddim: float = 0.0, normalize: bool = True, residual: bool = False,
+                   map_cond: bool = True, sampling_timesteps: Optional[int] = None, precision: str = "fp32",
+                   elide: bool = True) -> SimpleNamespace:
+    """The fields the CLI copies onto the model config (utils/args.py:154-183; str_base.py:1045-1053)."""
+    return SimpleNamespace(trajectory_dim=4, frame_stack=frame_stack, n_maps_token=788, maps_dim=256, map_cond=map_cond,
+                           beta_schedule=beta_schedule, diffusion_timesteps=diffusion_timesteps, objective=objective,
+                           ddim=ddim, normalize=normalize, residual=residual, trajectory_loss_rescale=1.0,
+                           sampling_timesteps=sampling_timesteps, precision=precision, elide=elide)

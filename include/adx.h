@@ -1,0 +1,171 @@
+/*
+ * adx.h -- C ABI of libadx.so: MI355X (gfx950) kernels and sampling engines for the
+ * trajectory-diffusion refinement path.
+ *
+ * The reference implements this path as Python/PyTorch modules; it has no FFI of its own.
+ * Each entry point below therefore names the reference *Python* interface it stands in for
+ * (paths relative to the reference tree).  A binding is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in _host;
+ *   - tensors are contiguous row-major float32 unless stated; timesteps are int64;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream);
+ *   - every function returns 0 (ADX_OK) or a negative/positive error code and records a message
+ *     retrievable with adx_last_error() (thread-local); no C++ exception crosses the boundary;
+ *   - work is enqueued on `stream` and NOT synchronised;
+ *   - an engine is bound to the device that was current when it was created and is not
+ *     re-entrant (the reference guards generate() with a mutex: run_simulation.py:736-748).
+ */
+#ifndef ADX_H_
+#define ADX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADX_ABI_VERSION 1
+
+enum { ADX_OK = 0, ADX_EINVAL = 1, ADX_ESTATE = 2, ADX_EHIP = 3, ADX_ENOMEM = 4, ADX_ENOTFOUND = 5 };
+
+enum { ADX_ACT_NONE = 0, ADX_ACT_RELU = 1, ADX_ACT_GELU_ERF = 2, ADX_ACT_GELU_TANH = 3, ADX_ACT_LEAKY = 4, ADX_ACT_SILU = 5 };
+enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1 };   /* GEMM operand type; accumulation is always f32 */
+enum { ADX_VARIANT_A = 0, ADX_VARIANT_DIT = 1, ADX_VARIANT_MMDIT = 2 };
+
+/* sampling flags */
+#define ADX_FLAG_NORMALIZE 1u   /* auto_normalize_data: utils.py:56-80 applied to prior/transition in, trajectory out */
+#define ADX_FLAG_RESIDUAL 2u    /* add the raw prior to the un-normalised sample (TrajRefiner.py:382-384) */
+#define ADX_FLAG_INIT_ZERO 4u   /* x_N = 0 instead of noise[0] (determin=True, diffusion_decoder.py:390-393) */
+#define ADX_FLAG_NO_GRAPH 8u    /* launch kernels eagerly instead of replaying a captured hipGraph */
+
+int adx_abi_version(void);
+const char* adx_last_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * Operator-level entry points (stateless).
+ * ------------------------------------------------------------------------------------------ */
+
+/* SinusoidalPosEmb.forward -- models/diffusion_loss/positional_embedding.py:10-17, libs/embeds.py:13-20.
+ * t[n] int64 -> out[n][dim] = [sin(t w), cos(t w)]. */
+int adx_op_timestep_embedding(const int64_t* t, int n, int dim, float* out, void* stream);
+
+/* torch.nn.Linear (+ fused activation): y[M][N] = act(x[M][K] w[N][K]^T + bias).  With
+ * ADX_PREC_BF16, `w` holds bf16 bit patterns (see adx_op_to_bf16) and x is rounded to bf16 as it
+ * is staged.  Stands in for every nn.Linear on the path (transformer.py:50,60-61,133;
+ * libs/diffusionTransformer.py:38-47,63-76,134-165,189-193; libs/mlp.py:28,50). */
+int adx_op_linear(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
+                  int prec, void* stream);
+int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+
+/* LayerNorm over the last axis, optionally affine (gamma/beta), optionally followed by the adaLN
+ * `modulate` x*(1+scale)+shift with per-row shift/scale of row stride ld_mod, optionally ReLU.
+ * nn.LayerNorm uses in transformer.py:132 and torch TransformerEncoder/DecoderLayer; custom LayerNorm
+ * libs/mlp.py:5-20; modulate + LayerNorm(elementwise_affine=False): libs/diffusionTransformer.py:19-20,30,35. */
+int adx_op_layernorm(const float* x, const float* gamma, const float* beta, const float* shift, const float* scale,
+                     int64_t ld_mod, float eps, int relu, int64_t rows, int d, float* y, void* stream);
+
+/* Multi-head softmax attention on contiguous q[B][Sq][H*dh], k[B][Skv][H*dh], v[B][Skv][H*dv] ->
+ * o[B][Sq][H*dv].  mask_off < 0: unmasked; otherwise key j is visible to query i iff j <= i + mask_off
+ * (0 = the causal tgt_mask, 1 = the memory_mask of transformer.py:106-124).
+ * torch.nn.MultiheadAttention core / DiT_Attention.forward (libs/diffusionTransformer.py:99-117). */
+int adx_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh,
+                     int dv, float scale, int mask_off, void* stream);
+
+/* normalize / denormalize -- models/utils.py:56-80 (C = 4 or 2 channels). `residual` may be NULL. */
+int adx_op_normalize(const float* x, float* y, int64_t n_points, int C, void* stream);
+int adx_op_denormalize(const float* y, const float* residual, float* x, int64_t n_points, int C, void* stream);
+
+/* One scheduler update over n elements.  All reference samplers reduce to this form:
+ *     x0   = clamp(a0*x + a1*model_out, -clip, +clip)
+ *     eps  = eps_mode ? (b0*x - x0) * b1 : model_out
+ *     x'   = c0*x0 + c1*x + c2*eps + c3*z
+ * DDPM p_sample (TrajRefiner.py:296-313; diffusion_decoder.py:434-479), DDIM ddim_sample
+ * (TrajRefiner.py:349-371), and the diffusers-style DDPM/DDIM steps of diffusion_transition.py:72-75 /
+ * traj_diffusion.py:76-78 differ only in the coefficients, which the host computes.
+ * `t` is the diffusion timestep fed to the denoiser; `z_index` selects noise[1 + z_index] (-1: none). */
+typedef struct adx_step_coef {
+    float t, a0, a1, clip, eps_mode, b0, b1, c0, c1, c2, c3, z_index;
+} adx_step_coef;
+int adx_op_sched_step(const float* x, const float* model_out, const float* z, float* x_next, float* x0_out, int64_t n,
+                      const adx_step_coef* coef_dev, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Engines: a denoiser (weights + workspace) plus the sampling loop, captured as one hipGraph.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct adx_engine adx_engine;
+
+typedef struct adx_model_config {
+    int variant;        /* ADX_VARIANT_* */
+    int precision;      /* ADX_PREC_* */
+    int elide;          /* 1: skip work whose result the masks make unobservable (exact in real arithmetic) */
+    int d_model;        /* n_emb (A) / feat_dim = n_embd (DiT) */
+    int n_head;
+    int n_enc_layers;   /* A: n_cond_layers */
+    int n_layers;       /* A: decoder layers; DiT: blocks */
+    int horizon;        /* A: T tokens per chunk; DiT: predict_range (80) */
+    int in_dim;         /* A: channels per token (4, or fs*4 when flattened); DiT: out_features (4) */
+    int out_dim;
+    int n_prior_tokens; /* A: P (= frame_stack, or 1 when flattened) */
+    int prior_dim;      /* A */
+    int n_maps_token;   /* A: 788 */
+    int maps_dim;       /* A: 256 */
+    int map_cond;       /* A */
+    int n_inner;        /* DiT: hidden width of state_encoder[0] */
+    int connect_dim;    /* DiT: width between the two state_encoder stages */
+} adx_model_config;
+
+int adx_engine_create(const adx_model_config* cfg, adx_engine** out);
+int adx_engine_destroy(adx_engine* e);
+
+/* Copy one parameter (float32, device memory) into the engine under its reference state_dict name,
+ * e.g. "encoder.layers.0.self_attn.in_proj_weight" (variant A: names of
+ * models/diffusion_loss/transformer.py::Transformer) or "blocks.3.adaLN_modulation.1.weight"
+ * (DiT: names of models/diffusion_loss/diffusion_decoder.py::Transformer_TrajDiffusionModel). */
+int adx_engine_set_tensor(adx_engine* e, const char* name, const float* data, const int64_t* shape_host, int ndim);
+/* Verify that every parameter the configured model needs is present with the right shape. */
+int adx_engine_finalize(adx_engine* e);
+/* (Re)allocate the activation workspace for batches up to max_batch rows. */
+int adx_engine_reserve(adx_engine* e, int max_batch);
+int64_t adx_engine_workspace_bytes(const adx_engine* e);
+
+/* Transformer.forward(noisy_x, timestep, condition) -- models/diffusion_loss/transformer.py:189-273.
+ * x[B][T][in_dim], t[B] int64, maps[B][n_maps][maps_dim], transition/prior[B][P][prior_dim] (already
+ * normalised, as the denoiser sees them) -> out[B][T][out_dim] (never squeezed). */
+int adx_denoise_a(adx_engine* e, int B, const float* x, const int64_t* t, const float* maps, const float* transition,
+                  const float* prior, float* out, void* stream);
+
+/* Transformer_TrajDiffusionModel.forward(x, t, state) -- models/diffusion_loss/diffusion_decoder.py:251-277.
+ * x[B][S][4], t[B] int64, state[B][S][d_model] -> out[B][S][4]. */
+int adx_denoise_dit(adx_engine* e, int B, const float* x, const int64_t* t, const float* state, float* out,
+                    void* stream);
+
+/* Per-step coefficient table of the sampler (host memory), in execution order. */
+int adx_engine_set_schedule(adx_engine* e, const adx_step_coef* steps_host, int n_steps);
+
+/* DiffusionWrapper.sample for one chunk -- TrajRefiner.py:315-386 (p_sample_loop / ddim_sample / sample).
+ * transition/prior are RAW (un-normalised) [B][P][prior_dim]; noise[(1+n_draws)][B][T][in_dim];
+ * out[B][T][in_dim].  trace_x / trace_out (nullable) receive x_t and the model output of every step,
+ * [n_steps][B][T][in_dim] each. */
+int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transition, const float* prior,
+                 const float* noise, int n_noise, float* out, float* trace_x, float* trace_out, unsigned flags,
+                 void* stream);
+
+/* Chunk loop of the generate() wrappers -- models/backbone/DiffusionAugmentation.py:137-195 (token layout)
+ * and models/backbone/ExplicitDiT.py:139-198 (flattened layout, config in_dim = frame_stack*4):
+ * prior_full[B][S][4] is cut into S/frame_stack chunks, each sampled with the previous chunk's output as
+ * transition_info (init_x[frame_stack][4] for the first), results re-assembled into out[B][S][4].
+ * noise[n_chunks][n_noise][B][T][in_dim]. */
+int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
+                   const float* init_x, const float* noise, int n_noise, float* out, unsigned flags, void* stream);
+
+/* DiffusionWrapper.sample_forward / p_sample_loop -- models/diffusion_loss/diffusion_decoder.py:377-446.
+ * state[B][S][d_model]; noise[n_noise][B][S][4] (may be NULL with ADX_FLAG_INIT_ZERO and a noise-free
+ * schedule); out[B][S][4] is de-normalised when ADX_FLAG_NORMALIZE is set. */
+int adx_sample_dit(adx_engine* e, int B, const float* state, const float* noise, int n_noise, float* out,
+                   unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADX_H_ */

@@ -1,0 +1,339 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (max |a-b| / max |b| per tensor):
+  * fp32 engine, one denoiser call / one sampling step: 1e-3 (the stated gate); observed ~1e-5..1e-4
+  * bf16 engine, final trajectories: ADE <= 1e-2 m against the fp32 oracle on the same noise
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ISEED, NSEED, WSEED, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GATE = 1e-3
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from autodiffusion_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ operators
+def test_op_timestep_embedding(dev, golden):
+    from autodiffusion_amd import ops
+    g = golden("g2_g3_misc")
+    t = T(g["posemb_t"]).to(dev)
+    for d in (32, 256, 1024):
+        e = ops.timestep_embedding(t, d).cpu().numpy()
+        np.testing.assert_allclose(e, g[f"posemb_a_{d}"], atol=5e-5)   # arguments reach 199 rad in f32
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (70, 32, 4), (809, 96, 32), (333, 32, 128), (160, 256, 68), (200, 130, 2816)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_op_linear(dev, M, N, K, prec):
+    from autodiffusion_amd import _lib, ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    for act, fn in ((_lib.ACT_NONE, lambda v: v), (_lib.ACT_GELU_ERF, torch.nn.functional.gelu),
+                    (_lib.ACT_GELU_TANH, lambda v: torch.nn.functional.gelu(v, approximate="tanh")),
+                    (_lib.ACT_RELU, torch.relu), (_lib.ACT_LEAKY, lambda v: torch.nn.functional.leaky_relu(v, 0.01))):
+        y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act, prec).cpu()
+        if prec == "bf16":
+            ref = fn(x.bfloat16().double() @ w.bfloat16().double().T + b.double()).float()
+            assert rel_err(y, ref) < 2e-5     # operands rounded identically; only f32 accumulation order differs
+        else:
+            ref = fn(x.double() @ w.double().T + b.double()).float()
+            assert rel_err(y, ref) < 2e-6
+
+
+def test_op_linear_asymmetric_identity(dev):
+    """A = I against an asymmetric W catches a transposed accumulator layout."""
+    from autodiffusion_amd import ops
+    n = 96
+    x = torch.eye(n)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 100.0
+    y = ops.linear(x.to(dev), w.to(dev), None).cpu()
+    assert torch.equal(y, w.T.contiguous())
+    yb = ops.linear(x.to(dev), w.to(dev), None, precision="bf16").cpu()
+    assert torch.equal(yb, w.T.contiguous())     # small integers are exact in bf16
+
+
+@pytest.mark.parametrize("d", [32, 64, 96, 256, 1000, 4096])
+def test_op_layernorm(dev, d):
+    from autodiffusion_amd import ops
+    from oracle import nets
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(37, d, generator=g) * 3 + 1
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    sh, sc = torch.randn(37, d, generator=g), torch.randn(37, d, generator=g)
+    y = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), eps=1e-5).cpu()
+    assert rel_err(y, nets.layer_norm(x, gamma, beta, 1e-5)) < 1e-5
+    y = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), eps=1e-5, relu=True).cpu()
+    assert rel_err(y, torch.relu(nets.layer_norm(x, gamma, beta, 1e-5))) < 1e-5
+    y = ops.layernorm(x.to(dev), shift=sh.to(dev), scale=sc.to(dev), eps=1e-6).cpu()
+    assert rel_err(y, nets.layer_norm(x, eps=1e-6) * (1 + sc) + sh) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,dh,mask", [(2, 8, 809, 809, 4, -1), (3, 8, 10, 10, 4, 0), (3, 8, 10, 11, 4, 1),
+                                                (2, 8, 11, 949, 4, -1), (2, 4, 80, 80, 16, -1), (2, 8, 80, 80, 32, -1),
+                                                (1, 4, 80, 80, 128, -1), (1, 2, 80, 80, 512, -1), (2, 2, 33, 70, 40, 1)])
+def test_op_attention(dev, B, H, Sq, Skv, dh, mask):
+    from autodiffusion_amd import ops
+    from oracle import nets
+    g = torch.Generator().manual_seed(Sq + dh)
+    q = torch.randn(B, Sq, H * dh, generator=g)
+    k = torch.randn(B, Skv, H * dh, generator=g)
+    v = torch.randn(B, Skv, H * dh, generator=g)
+    allowed = None
+    if mask >= 0:
+        allowed = torch.arange(Skv)[None, :] <= torch.arange(Sq)[:, None] + mask
+    ref = nets.attention(q, k, v, H, allowed)
+    o = ops.attention(q.to(dev), k.to(dev), v.to(dev), H, mask_off=mask).cpu()
+    assert rel_err(o, ref) < 2e-5
+
+
+def test_op_normalize_sched_step(dev, golden):
+    from autodiffusion_amd import ops, schedules
+    from oracle import sampling
+    g = golden("g2_g3_misc")
+    x = T(g["x"]).to(dev)
+    np.testing.assert_allclose(ops.normalize(x).cpu().numpy(), g["normalize"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ops.denormalize(x).cpu().numpy(), g["denormalize"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ops.denormalize(x, x).cpu().numpy(), g["denormalize"] + g["x"], rtol=1e-6, atol=1e-5)
+    x2 = x[..., :2].contiguous()
+    np.testing.assert_allclose(ops.normalize(x2).cpu().numpy(), g["normalize2"], rtol=1e-6, atol=1e-6)
+    # one DDPM step against the oracle's update, every objective
+    gen = torch.Generator().manual_seed(1)
+    xt, out, z = (torch.randn(5, 10, 4, generator=gen) for _ in range(3))
+    from oracle import schedules as osched
+    for obj in ("pred_noise", "pred_x0", "pred_v"):
+        b = schedules.diffusion_buffers(schedules.make_betas("cosine", 10))
+        rows = schedules.ddpm_rows(b, obj)
+        ob = osched.buffers("cosine", 10, obj)
+        for row in (rows[0], rows[5], rows[-1]):
+            t = int(row[0])
+            x0 = sampling.x0_from_output(ob, obj, xt, out, t).clamp(-300, 300)
+            mean = float(ob["posterior_mean_coef1"][t]) * x0 + float(ob["posterior_mean_coef2"][t]) * xt
+            ref = mean + (np.exp(0.5 * ob["posterior_log_variance_clipped"][t]) * z if t > 0 else 0)
+            got, gx0 = ops.sched_step(xt.to(dev), out.to(dev), z.to(dev), row, want_x0=True)
+            assert rel_err(got.cpu(), ref) < 1e-5
+            assert rel_err(gx0.cpu(), x0) < 1e-5
+
+
+# ------------------------------------------------------------------ variant A
+def make_a(fs, flat=False, precision="fp32", elide=True, dev="cuda:0"):
+    from autodiffusion_amd import refiner, synth
+    if flat:
+        m = refiner.Transformer(input_dim=4 * fs, output_dim=4 * fs, horizon=1, n_cond_steps=788, cond_dim=256, n_prior_steps=1,
+                                prior_dim=4 * fs, causal_attn=True, map_cond=True, precision=precision, elide=elide)
+    else:
+        m = refiner.Transformer(input_dim=4, output_dim=4, horizon=fs, n_cond_steps=788, cond_dim=256, n_prior_steps=fs,
+                                prior_dim=4, causal_attn=True, map_cond=True, precision=precision, elide=elide)
+    synth.fill_module_(m, WSEED)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("tag,fs,flat", [("fs10", 10, False), ("fs80", 80, False), ("flat10", 10, True)])
+@pytest.mark.parametrize("elide", [False, True])
+def test_variant_a_single_call(dev, golden, tag, fs, flat, elide):
+    from autodiffusion_amd import synth
+    g = golden(f"g4_variant_a_{tag}")
+    m = make_a(fs, flat, elide=elide)
+    maps = synth.maps_info(2, ISEED).to(dev)
+    cond = dict(maps_info=maps, transition_info=T(g["transition_info"]).to(dev), trajectory_prior=T(g["trajectory_prior"]).to(dev))
+    out = m(T(g["x"]).to(dev), T(g["t"]).to(dev), cond)
+    assert out.shape == g["out"].shape
+    e = rel_err(out.cpu(), g["out"])
+    print(f"variant A {tag} elide={elide}: rel err {e:.2e}")
+    assert e < GATE
+
+
+def test_variant_a_state_dict_layout(dev):
+    """The parameter/buffer names are the reference's (110 entries for fs=10)."""
+    m = make_a(10)
+    keys = list(m.state_dict().keys())
+    assert len(keys) == 110
+    for k in ("pos_emb", "cond_pos_emb", "mask", "memory_mask", "input_emb.weight", "cond_obs_emb.bias", "prior_z_emb.weight",
+              "encoder.layers.1.self_attn.in_proj_weight", "decoder.layers.3.multihead_attn.out_proj.bias",
+              "decoder.layers.0.norm3.weight", "ln_f.bias", "head.weight"):
+        assert k in keys
+    assert tuple(m.state_dict()["memory_mask"].shape) == (10, 809)
+    assert (m.state_dict()["memory_mask"] == 0).sum(1).tolist() == list(range(2, 12))
+
+
+@pytest.mark.parametrize("obj", ["pred_noise", "pred_x0", "pred_v"])
+@pytest.mark.parametrize("sched", ["cosine", "sigmoid"])
+def test_ddpm_loop_trace(dev, golden, obj, sched):
+    from autodiffusion_amd import refiner, synth
+    g = golden("g6_g7_loops")
+    w = refiner.DiffusionWrapper(make_a(10), timesteps=10, objective=obj, beta_schedule=sched).to(dev).eval()
+    noise = synth.noise(2, (11,), (10, 4), NSEED)[:10].contiguous().to(dev)   # init + 9 draws
+    cond = dict(maps_info=synth.maps_info(2, ISEED).to(dev), transition_info=T(g["transition_info"]).to(dev),
+                trajectory_prior=T(g["trajectory_prior"]).to(dev))
+    before = {k: v.clone() for k, v in cond.items()}
+    res, tx, to = w.sample(cond, torch.zeros(2, 10, 4), noise=noise, trace=True)
+    for k in cond:                                  # caller tensors untouched
+        assert torch.equal(cond[k], before[k])
+    x_ref, o_ref = g[f"ddpm_{obj}_{sched}_x"], g[f"ddpm_{obj}_{sched}_model_out"]
+    worst = 0.0
+    for i in range(10):
+        worst = max(worst, rel_err(tx[i].cpu(), x_ref[i]), rel_err(to[i].cpu(), o_ref[i]))
+    print(f"ddpm {obj} {sched}: worst per-step rel err {worst:.2e}")
+    assert worst < GATE
+    assert rel_err(res.cpu(), g[f"ddpm_{obj}_{sched}_result"]) < GATE
+
+
+@pytest.mark.parametrize("obj", ["pred_noise", "pred_x0"])
+@pytest.mark.parametrize("eta", [0, 1])
+def test_ddim_loop_trace(dev, golden, obj, eta):
+    from autodiffusion_amd import refiner, synth
+    g = golden("g6_g7_loops")
+    w = refiner.DiffusionWrapper(make_a(10), timesteps=10, sampling_timesteps=5, objective=obj, beta_schedule="cosine",
+                                 ddim_sampling_eta=float(eta)).to(dev).eval()
+    assert w.is_ddim_sampling
+    noise = synth.noise(2, (6,), (10, 4), NSEED)[:5].contiguous().to(dev)
+    cond = dict(maps_info=synth.maps_info(2, ISEED).to(dev), transition_info=T(g["transition_info"]).to(dev),
+                trajectory_prior=T(g["trajectory_prior"]).to(dev))
+    res, tx, to = w.sample(cond, torch.zeros(2, 10, 4), noise=noise, trace=True)
+    x_ref = g[f"ddim_{obj}_eta{eta}_x"]
+    for i in range(5):
+        assert rel_err(tx[i].cpu(), x_ref[i]) < GATE, i
+    assert rel_err(res.cpu(), g[f"ddim_{obj}_eta{eta}_result"]) < GATE
+
+
+@pytest.mark.parametrize("tag,fs,residual,obj,sched", [("fs10", 10, False, "pred_noise", "cosine"),
+                                                       ("fs10_res", 10, True, "pred_x0", "sigmoid"),
+                                                       ("fs80", 80, True, "pred_x0", "sigmoid")])
+@pytest.mark.parametrize("graph", [True, False])
+def test_generate_chunk_loop(dev, golden, tag, fs, residual, obj, sched, graph):
+    from autodiffusion_amd import _lib, refiner, synth
+    g = golden("g8_chunk_loop")
+    cfg = refiner.refiner_config(frame_stack=fs, diffusion_timesteps=10, objective=obj, beta_schedule=sched, residual=residual)
+    da = refiner.DiffusionAugmentation(cfg)
+    synth.fill_module_(da.diffusion, WSEED)
+    with torch.no_grad():
+        da.init_x.copy_(synth.seeded_param("init_x", (fs, 4), WSEED))
+    da = da.to(dev).eval()
+    noise = synth.noise(2, (80 // fs, 11), (fs, 4), NSEED)[:, :10].contiguous().to(dev)
+    prior = synth.trajectory_prior(2, ISEED).to(dev)
+    maps = synth.maps_info(2, ISEED).to(dev)
+    if not graph:
+        w = da.diffusion.diffusion
+        w.flags = (lambda f=w.flags: f() | _lib.FLAG_NO_GRAPH)
+    out = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"]
+    assert out.shape == (2, 80, 4) and out.dtype == torch.float32
+    e = rel_err(out.cpu(), g[f"{tag}_traj"])
+    print(f"generate {tag} graph={graph}: rel err {e:.2e}")
+    assert e < GATE
+    out2 = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"]
+    assert torch.equal(out, out2), "sampling with fixed noise must be bit-for-bit reproducible"
+    with pytest.raises(ValueError):
+        da.generate(trajectory_prior=prior[:, :75].contiguous(), maps_info=maps, noise=noise)
+
+
+def test_shard_invariance_and_bf16_ade(dev):
+    """Rows do not depend on their batch neighbours (what multi-GPU sharding relies on); bf16 stays within 1e-2 m ADE."""
+    from autodiffusion_amd import metrics, refiner, synth
+    from oracle import nets, sampling, schedules as osched
+    fs, B, N = 10, 6, 10
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        cfg = refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective="pred_noise", beta_schedule="cosine",
+                                     precision=prec)
+        da = refiner.DiffusionAugmentation(cfg)
+        synth.fill_module_(da.diffusion, WSEED)
+        with torch.no_grad():
+            da.init_x.copy_(synth.seeded_param("init_x", (fs, 4), WSEED))
+        da = da.to(dev).eval()
+        noise = synth.noise(B, (8, N), (fs, 4), NSEED).to(dev)
+        prior = synth.trajectory_prior(B, ISEED).to(dev)
+        maps = synth.maps_info(B, ISEED).to(dev)
+        full = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"]
+        parts = []
+        for lo, hi in ((0, 2), (2, 6)):
+            parts.append(da.generate(trajectory_prior=prior[lo:hi].contiguous(), maps_info=maps[lo:hi].contiguous(),
+                                     noise=noise[:, :, lo:hi].contiguous())["traj_logits"])
+        assert torch.equal(full, torch.cat(parts)), f"{prec}: sharded run differs from the single run"
+        outs[prec] = full.cpu()
+    # fp32 oracle on the same inputs
+    from test_oracle_golden import variant_a_sd
+    sd = variant_a_sd(fs, prefix="diffusion.model.")
+    maps_c = synth.maps_info(B, ISEED)
+
+    def fn(x, t, tra_n, pri_n):
+        tt = torch.full((x.shape[0],), int(t), dtype=torch.long)
+        return nets.variant_a_forward(sd, x, tt, maps_c, tra_n, pri_n)
+    ref = sampling.refiner_generate(fn, osched.buffers("cosine", N, "pred_noise"), "pred_noise", maps_c,
+                                    synth.trajectory_prior(B, ISEED), synth.seeded_param("init_x", (fs, 4), WSEED),
+                                    synth.noise(B, (8, N), (fs, 4), NSEED), fs)
+    ade32 = float(metrics.ade_fde(outs["fp32"], ref)["ade8"].max())
+    ade16 = float(metrics.ade_fde(outs["bf16"], ref)["ade8"].max())
+    print(f"ADE vs fp32 oracle: fp32 engine {ade32:.3e} m, bf16 engine {ade16:.3e} m")
+    assert ade32 < 1e-3
+    assert ade16 < 1e-2
+
+
+# ------------------------------------------------------------------ variant B
+@pytest.mark.parametrize("tag,d,L,h", [("mini", 64, 2, 4), ("d256", 256, 4, 8)])
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_dit_single_call(dev, golden, tag, d, L, h, backbone):
+    from autodiffusion_amd import dit, synth
+    g = golden(f"g5_{backbone.replace('-', '').lower()}_{tag}")
+    m = dit.Transformer_TrajDiffusionModel(dit.dit_config(d, L, h, backbone))
+    synth.fill_module_(m, WSEED)
+    m = m.to(dev).eval()
+    out = m(T(g["x"]).to(dev), T(g["t"]).to(dev), synth.hidden_state(2, d, ISEED).to(dev))
+    e = rel_err(out.cpu(), g["out"])
+    print(f"{backbone} {tag}: rel err {e:.2e}")
+    assert e < GATE
+
+
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_dit_loop(dev, golden, backbone):
+    from autodiffusion_amd import dit, synth
+    g = golden("g9_dit_loop")
+    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, backbone, diffusion_timesteps=10))
+    synth.fill_module_(dec, WSEED)
+    dec = dec.to(dev).eval()
+    state = synth.hidden_state(2, 64, ISEED).to(dev)
+    det = dec.generate(state)
+    assert rel_err(det.cpu(), g[f"{backbone}_determin"]) < GATE
+    noise = synth.noise(2, (11,), (80, 4), NSEED).to(dev)
+    sto, cls = dec.model(state, batch_size=2, determin=False, noise=noise, return_scores=True)
+    assert rel_err(sto.cpu(), g[f"{backbone}_stochastic"]) < GATE
+    np.testing.assert_allclose(cls.cpu().numpy(), -(noise.cpu() ** 2).mean(dim=2).sum(0).numpy(), rtol=1e-5)
+    # multi-sample path: (B, mc, S, C); sample m of scenario b is row b*mc+m of the flat batch
+    mc = 3
+    nz = synth.noise(2 * mc, (11,), (80, 4), NSEED).to(dev)
+    multi = dec.model(state, batch_size=2, determin=False, mc_num=mc, noise=nz)
+    assert multi.shape == (2, mc, 80, 4)
+    single = dec.model(state[1:2].contiguous(), batch_size=1, determin=False, noise=nz[:, 4:5].contiguous())
+    assert torch.equal(multi[1, 1], single[0])
+
+
+def test_errors(dev):
+    from autodiffusion_amd import _lib, refiner
+    from autodiffusion_amd.engine import Engine
+    eng = Engine(variant=_lib.VARIANT_A, precision=0, elide=1, d_model=32, n_head=8, n_enc_layers=2, n_layers=4, horizon=10,
+                 in_dim=4, out_dim=4, n_prior_tokens=10, prior_dim=4, n_maps_token=788, maps_dim=256, map_cond=1)
+    with pytest.raises(_lib.AdxError, match="missing parameter"):
+        eng.load([("pos_emb", torch.zeros(1, 10, 32, device=dev))])
+    with pytest.raises(_lib.AdxError):
+        Engine(variant=7, precision=0, d_model=32, n_head=8, n_layers=1, horizon=1, in_dim=4, out_dim=4)
+    with pytest.raises(_lib.AdxError, match="device memory"):
+        _lib.ptr(torch.zeros(3))
+    w = refiner.DiffusionWrapper(make_a(10), timesteps=10).eval()
+    w.train()
+    with pytest.raises(NotImplementedError):
+        w({}, torch.zeros(1, 10, 4))

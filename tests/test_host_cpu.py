@@ -1,0 +1,210 @@
+"""CPU-only checks of the host side: schedule tables, C-ABI surface, module layout, sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from autodiffusion_amd import _lib, schedules
+from oracle import sampling, schedules as osched
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def apply_row(row, x, out, z):
+    """The scheduler update of include/adx.h (adx_step_coef), in float32 torch."""
+    t, a0, a1, clip, eps_mode, b0, b1, c0, c1, c2, c3, zi = [np.float32(v) for v in row]
+    f = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+    x0 = (f(a0) * x + f(a1) * out).clamp(-float(clip), float(clip))
+    eps = (f(b0) * x - x0) * f(b1) if eps_mode != 0 else out
+    r = f(c0) * x0 + f(c1) * x + f(c2) * eps
+    if c3 != 0:
+        r = r + f(c3) * z
+    return r
+
+
+def run_rows(rows, denoise, noise):
+    x = noise[0].clone()
+    for row in rows:
+        zi = int(row[11])
+        x = apply_row(row, x, denoise(x, int(row[0])), noise[1 + zi] if zi >= 0 else None)
+    return x
+
+
+def fake_denoiser(x, t):
+    return torch.tanh(x * 0.7 + 0.01 * t) - 0.2 * x
+
+
+@pytest.mark.parametrize("sched", ["sigmoid", "cosine", "linear"])
+@pytest.mark.parametrize("n", [10, 50, 100, 200])
+def test_product_buffers_match_golden(golden, sched, n):
+    g = golden("g1_schedules")
+    b = schedules.diffusion_buffers(schedules.make_betas(sched, n))
+    for k in schedules.BUFFER_NAMES:
+        np.testing.assert_allclose(b[k].numpy(), g[f"{sched}_{n}_{k}"], rtol=2e-6, atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize("obj", ["pred_noise", "pred_x0", "pred_v"])
+def test_ddpm_rows_reproduce_the_loop(obj):
+    n = 20
+    b = schedules.diffusion_buffers(schedules.make_betas("cosine", n))
+    rows = schedules.ddpm_rows(b, obj)
+    assert [int(r[0]) for r in rows] == list(reversed(range(n)))
+    assert schedules.n_noise_draws(rows) == n - 1 and rows[-1][11] == -1
+    noise = torch.randn(n, 3, 10, 4, generator=torch.Generator().manual_seed(0))
+    got = run_rows(rows, fake_denoiser, noise)
+    ref = sampling.ddpm_sample(fake_denoiser, osched.buffers("cosine", n, obj), obj, noise)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("obj", ["pred_noise", "pred_x0", "pred_v"])
+@pytest.mark.parametrize("eta", [0.0, 1.0])
+def test_ddim_rows_reproduce_the_loop(obj, eta):
+    n, ns = 100, 50
+    b = schedules.diffusion_buffers(schedules.make_betas("cosine", n))
+    rows = schedules.ddim_rows(b, obj, ns, eta)
+    assert len(rows) == ns and schedules.n_noise_draws(rows) == ns - 1
+    assert schedules.ddim_time_pairs(10, 5) == sampling.ddim_pairs(10, 5)
+    noise = torch.randn(ns, 3, 10, 4, generator=torch.Generator().manual_seed(0))
+    got = run_rows(rows, fake_denoiser, noise)
+    ref = sampling.ddim_sample(fake_denoiser, osched.buffers("cosine", n, obj), obj, noise, ns, eta)
+    assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5)
+
+
+def test_twin_and_diffusers_rows():
+    n = 10
+    b = schedules.diffusion_buffers(schedules.cosine_beta_schedule(n))
+    ob = osched.buffers_from_betas(osched.twin_betas("cosine", n))
+    noise = torch.randn(n + 1, 2, 80, 4, generator=torch.Generator().manual_seed(0))
+    rows = schedules.ddpm_rows(b, "pred_noise", clamp=100.0, noise_at_every_step=True, stochastic=True)
+    assert schedules.n_noise_draws(rows) == n
+    got = sampling.denormalize(run_rows(rows, fake_denoiser, noise))
+    ref, _ = sampling.twin_sample(fake_denoiser, ob, (2, 80, 4), noise, determin=False)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4)
+    rows = schedules.ddpm_rows(b, "pred_noise", clamp=100.0, noise_at_every_step=True, stochastic=False)
+    assert schedules.n_noise_draws(rows) == 0
+    got = sampling.denormalize(run_rows(rows, fake_denoiser, torch.zeros(1, 2, 80, 4)))
+    ref, _ = sampling.twin_sample(fake_denoiser, ob, (2, 80, 4), None, determin=True)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4)
+    # diffusers-style rows against the oracle's step functions
+    betas = schedules.diffusers_betas("squaredcos_cap_v2", 100)
+    ac = np.cumprod(1.0 - osched.squaredcos_cap_v2(100).astype(np.float64))
+    for kind in ("ddim", "ddpm"):
+        rows = schedules.diffusers_rows(betas, 10, kind)
+        assert [int(r[0]) for r in rows] == sampling.diffusers_timesteps(100, 10)
+        x = noise[0, :, :1, :].clone()
+        xr = x.clone()
+        k = 1
+        for row in rows:
+            t = int(row[0])
+            eps = fake_denoiser(x, t)
+            zi = int(row[11])
+            x = apply_row(row, x, eps, noise[1 + zi, :, :1, :] if zi >= 0 else None)
+            epr = fake_denoiser(xr, t)
+            if kind == "ddim":
+                xr = sampling.diffusers_ddim_step(ac, 10, epr, t, xr)
+            else:
+                xr = sampling.diffusers_ddpm_step(ac, 10, epr, t, xr, noise[k, :, :1, :])
+                k += 1
+        assert torch.allclose(x, xr, rtol=1e-4, atol=1e-5), kind
+
+
+def test_library_exports_every_declared_symbol():
+    """libadx.so loads without a GPU and exports exactly what include/adx.h declares."""
+    assert os.path.exists(_lib.LIB_PATH), "build libadx.so first: python -m autodiffusion_amd.build"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "adx.h")).read()
+    declared = sorted(set(re.findall(r"\b(adx_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in adx.h but not exported"
+    assert sorted(declared) == sorted(_lib.EXPORTS)
+    lib.adx_abi_version.restype = ctypes.c_int
+    assert lib.adx_abi_version() == 1
+    assert ctypes.sizeof(_lib.StepCoef) == 48 and ctypes.sizeof(_lib.ModelConfig) == 17 * 4
+
+
+def test_product_does_not_import_the_oracle():
+    """No CPU fallback: the package never references oracle/ and fails loudly without a GPU."""
+    pkg = os.path.join(ROOT, "autodiffusion_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+    if not torch.cuda.is_available():
+        from autodiffusion_amd.engine import Engine
+        with pytest.raises(_lib.AdxError, match="no GPU"):
+            Engine(variant=0)
+
+
+def test_module_layouts_match_reference_names():
+    from autodiffusion_amd import dit, refiner
+    cfg = refiner.refiner_config(frame_stack=10, diffusion_timesteps=10)
+    da = refiner.DiffusionAugmentation(cfg)
+    keys = set(da.state_dict().keys())
+    for k in ("init_x", "diffusion.diffusion.betas", "diffusion.diffusion.loss_weight", "diffusion.diffusion.posterior_mean_coef2",
+              "diffusion.diffusion.model.cond_pos_emb", "diffusion.diffusion.model.memory_mask",
+              "diffusion.diffusion.model.decoder.layers.2.multihead_attn.in_proj_weight"):
+        assert k in keys, k
+    assert sum(p.numel() for p in da.diffusion.diffusion.model.parameters()) == 128324   # measured on the reference at fs=10
+    m = dit.Transformer_TrajDiffusionModel(dit.dit_config(64, 2, 4, "MM-DiT"))
+    names = dict(m.named_parameters())
+    for k in ("blocks.1.attn.Wq_c.weight", "blocks.0.attn.ResNorm_x_q.weight", "blocks.0.adaLN_modulation_c.1.bias",
+              "blocks.0.mlp_x.2.weight", "state_encoder.1.mlp.layer_norm.weight", "x_encoder.3.fc.weight", "time_encoder.5.bias",
+              "final_layer.adaLN_modulation.1.weight", "position_embedding"):
+        assert k in names, k
+    assert tuple(names["blocks.0.attn.proj.weight"].shape) == (64, 2 * 64 * 4)
+    m = dit.Transformer_TrajDiffusionModel(dit.dit_config(256, 4, 8, "DiT"))
+    n = sum(p.numel() for p in m.parameters())
+    assert abs(n - 13.1e6) < 0.1e6, n                                                   # 13.1 M measured on the reference
+    with pytest.raises(ValueError):
+        dit.Transformer_TrajDiffusionModel(dit.dit_config(64, 2, 4, "DDPM"))
+    with pytest.raises(AssertionError):
+        refiner.DiffusionWrapper(torch.nn.Identity(), timesteps=10, objective="pred_eps")
+    with pytest.raises(ValueError):
+        refiner.DiffusionWrapper(torch.nn.Identity(), timesteps=10, beta_schedule="quadratic")
+
+
+def test_shard_range():
+    from autodiffusion_amd.distributed import shard_range
+    for total in (1, 7, 8, 1024, 4099):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from autodiffusion_amd import synth
+from autodiffusion_amd.distributed import shard_range, all_gather_rows
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+rank, world, total = dist.get_rank(), 2, 7
+lo, hi = shard_range(total, rank, world)
+# each rank builds only its own rows (global-row-indexed noise), "samples" them, then gathers
+local = synth.noise(hi - lo, (), (80, 4), 1234, row0=lo) * 2.0 + 1.0
+full = all_gather_rows(local, total)
+ref = synth.noise(total, (), (80, 4), 1234) * 2.0 + 1.0
+assert full.shape == ref.shape and torch.equal(full, ref), "gathered shards differ from the single-process result"
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
