@@ -9,7 +9,7 @@
 namespace adx {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU_ERF = 2, ACT_GELU_TANH = 3, ACT_LEAKY = 4, ACT_SILU = 5 };
-enum Prec : int { PREC_F32 = 0, PREC_BF16 = 1 };
+enum Prec : int { PREC_F32 = 0, PREC_BF16 = 1, PREC_BF16X3 = 2 };
 
 // Row index map: logical row m of an (M x N) operand lives at physical row
 //   (m / per_batch) * batch_stride + (m % per_batch) + off      (identity when per_batch == 0).
@@ -22,7 +22,8 @@ struct RowMap {
 // Y = res + gate * act(X W^T + bias + pos)        (each term optional)
 struct LinearArgs {
     const float* X = nullptr; int64_t ldx = 0; RowMap xmap;
-    const void* W = nullptr;            // [N][K] row-major; float (PREC_F32) or bf16 bits (PREC_BF16)
+    const void* W = nullptr;            // [N][K] row-major; float (PREC_F32) or bf16 bits (PREC_BF16 / PREC_BF16X3: high halves)
+    const void* Wlo = nullptr;          // PREC_BF16X3: bf16 bits of w - bf16(w)
     const float* bias = nullptr;        // [N]
     float* Y = nullptr; int64_t ldy = 0; RowMap ymap;
     int M = 0, N = 0, K = 0;
@@ -91,8 +92,8 @@ struct StepCoef { float t, a0, a1, clip, eps_mode, b0, b1, c0, c1, c2, c3, z_ind
 hipError_t sched_step(const float* x, const float* model_out, const float* z, float* x_next, float* x0_out,
                       int64_t n, const StepCoef* coef_dev, hipStream_t stream);
 
-// f32 -> bf16 (round to nearest even)
-hipError_t to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
+// f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
+hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);
 // strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)
 hipError_t copy2d(const float* src, int64_t lds, int64_t src_rows, float* dst, int64_t ldd, int64_t rows, int cols,
                   hipStream_t stream);

@@ -28,6 +28,7 @@ int hip_fail(hipError_t e, const char* what);
 struct Param {
     float* f32 = nullptr;
     uint16_t* bf16 = nullptr;
+    uint16_t* bf16lo = nullptr;   // bf16(w - bf16(w)), for the split-operand GEMM
     std::vector<int64_t> shape;
     int64_t numel = 0;
 };
@@ -76,12 +77,12 @@ struct adx_engine {
     // parameter access
     const adx::Param* find(const std::string& name) const;
     const float* P(const std::string& name) const;                         // f32 pointer (biases, gains, tables)
-    const void* W(const std::string& name, int64_t row0 = 0) const;          // GEMM operand in the engine precision
+    const void* W(const std::string& name, int64_t row0, int prec) const;     // GEMM operand: f32 or bf16 copy
     bool has(const std::string& name) const { return params.count(name) != 0; }
 
-    // y = act(x W[row0:row0+N]^T + b[row0:row0+N]) helper
+    // y = act(x W[row0:row0+N]^T + b[row0:row0+N]) helper; prec < 0 selects the engine precision
     adx::LinearArgs lin(const float* X, int64_t ldx, const std::string& wname, int64_t row0, int N, int K,
-                        const std::string& bname, float* Y, int64_t ldy, int M, int act = adx::ACT_NONE) const;
+                        const std::string& bname, float* Y, int64_t ldy, int M, int act = adx::ACT_NONE, int prec = -1) const;
 
     template <class F>
     int run(const std::string& key, unsigned flags, hipStream_t stream, F&& body);

@@ -12,6 +12,11 @@
 // i see memory rows 0..i+1 only, so (a) cross-attention keys/values are projected for rows 0..T alone and
 // (b) the last encoder layer evaluates queries, output projection and FFN for rows 0..T alone (its keys
 // and values still cover all L rows).  Exact in real arithmetic; no summation is reordered.
+//
+// Precision policy with ADX_PREC_BF16: bf16 MFMA operands where the FLOPs are -- the map-token embedding and
+// the encoder over the L conditioning rows.  Everything on the T-token trajectory path (the 4-wide input /
+// prior embeddings, the whole decoder, the head) and the scheduler state stay fp32: they are <10 % of the work,
+// and trajectory coordinates rounded to 8 mantissa bits would already cost decimetres.
 #include "engine.h"
 
 #include <math.h>
@@ -104,7 +109,7 @@ struct EngineA final : adx_engine {
     int embed_prior(int B, const float* tran_n, const float* prior_n, hipStream_t s) {
         for (int which = 0; which < 2; ++which) {
             const int off = 1 + nmaps + which * NP;
-            LinearArgs a = lin(which ? prior_n : tran_n, Cp, "prior_z_emb.weight", 0, d, Cp, "prior_z_emb.bias", X0, d, B * NP);
+            LinearArgs a = lin(which ? prior_n : tran_n, Cp, "prior_z_emb.weight", 0, d, Cp, "prior_z_emb.bias", X0, d, B * NP, ACT_NONE, PREC_F32);
             a.ymap = RowMap{NP, L, off};
             a.pos = P("cond_pos_emb"); a.ldp = d; a.pos_period = NP; a.pos_off = off;
             ADX_HIP(linear(a, s));
@@ -171,7 +176,7 @@ struct EngineA final : adx_engine {
         const float* memory = cur;   // (B, L, d); with elide only rows 0..T of each item are defined
         // ---- decoder (pre-norm, GELU): causal self-attention, masked cross-attention, FFN
         {
-            LinearArgs e = lin(x, Cin, "input_emb.weight", 0, d, Cin, "input_emb.bias", Y, d, B * T);
+            LinearArgs e = lin(x, Cin, "input_emb.weight", 0, d, Cin, "input_emb.bias", Y, d, B * T, ACT_NONE, PREC_F32);
             e.pos = P("pos_emb"); e.ldp = d; e.pos_period = T; e.pos_off = 0;
             ADX_HIP(linear(e, s));
         }
@@ -179,7 +184,7 @@ struct EngineA final : adx_engine {
         for (int i = 0; i < n_dec; ++i) {
             const std::string p = "decoder.layers." + std::to_string(i);
             ADX_TRY(ln_rows(Y, YN, p + ".norm1", B * T, RowMap{}, s));
-            ADX_HIP(linear(lin(YN, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", DQKV, 3 * d, B * T), s));
+            ADX_HIP(linear(lin(YN, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", DQKV, 3 * d, B * T, ACT_NONE, PREC_F32), s));
             AttentionArgs sa;
             sa.Q = DQKV; sa.K = DQKV + d; sa.V = DQKV + 2 * d;
             sa.ldq = sa.ldk = sa.ldv = 3 * d;
@@ -187,13 +192,13 @@ struct EngineA final : adx_engine {
             sa.O = DATT; sa.ldo = d; sa.o_batch_stride = (int64_t)T * d;
             sa.B = B; sa.H = H; sa.Sq = T; sa.Skv = T; sa.dh = dh; sa.dv = dh; sa.scale = scale; sa.mask_off = 0;
             ADX_HIP(attention(sa, s));
-            LinearArgs o = lin(DATT, d, p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias", Y, d, B * T);
+            LinearArgs o = lin(DATT, d, p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias", Y, d, B * T, ACT_NONE, PREC_F32);
             o.res = Y; o.ldr = d;
             ADX_HIP(linear(o, s));
             // cross attention
             ADX_TRY(ln_rows(Y, YN, p + ".norm2", B * T, RowMap{}, s));
-            ADX_HIP(linear(lin(YN, d, p + ".multihead_attn.in_proj_weight", 0, d, d, p + ".multihead_attn.in_proj_bias", DQ, d, B * T), s));
-            LinearArgs kv = lin(memory, d, p + ".multihead_attn.in_proj_weight", d, 2 * d, d, p + ".multihead_attn.in_proj_bias", MKV, 2 * d, B * Lm);
+            ADX_HIP(linear(lin(YN, d, p + ".multihead_attn.in_proj_weight", 0, d, d, p + ".multihead_attn.in_proj_bias", DQ, d, B * T, ACT_NONE, PREC_F32), s));
+            LinearArgs kv = lin(memory, d, p + ".multihead_attn.in_proj_weight", d, 2 * d, d, p + ".multihead_attn.in_proj_bias", MKV, 2 * d, B * Lm, ACT_NONE, PREC_F32);
             kv.xmap = mmap;                       // memory rows 0..Lm-1 of each item -> dense (B*Lm) rows
             ADX_HIP(linear(kv, s));
             AttentionArgs ca;
@@ -202,18 +207,18 @@ struct EngineA final : adx_engine {
             ca.O = DATT; ca.ldo = d; ca.o_batch_stride = (int64_t)T * d;
             ca.B = B; ca.H = H; ca.Sq = T; ca.Skv = Lm; ca.dh = dh; ca.dv = dh; ca.scale = scale; ca.mask_off = 1;
             ADX_HIP(attention(ca, s));
-            LinearArgs o2 = lin(DATT, d, p + ".multihead_attn.out_proj.weight", 0, d, d, p + ".multihead_attn.out_proj.bias", Y, d, B * T);
+            LinearArgs o2 = lin(DATT, d, p + ".multihead_attn.out_proj.weight", 0, d, d, p + ".multihead_attn.out_proj.bias", Y, d, B * T, ACT_NONE, PREC_F32);
             o2.res = Y; o2.ldr = d;
             ADX_HIP(linear(o2, s));
             // FFN
             ADX_TRY(ln_rows(Y, YN, p + ".norm3", B * T, RowMap{}, s));
-            ADX_HIP(linear(lin(YN, d, p + ".linear1.weight", 0, 4 * d, d, p + ".linear1.bias", DFF, 4 * d, B * T, ACT_GELU_ERF), s));
-            LinearArgs f2 = lin(DFF, 4 * d, p + ".linear2.weight", 0, d, 4 * d, p + ".linear2.bias", Y, d, B * T);
+            ADX_HIP(linear(lin(YN, d, p + ".linear1.weight", 0, 4 * d, d, p + ".linear1.bias", DFF, 4 * d, B * T, ACT_GELU_ERF, PREC_F32), s));
+            LinearArgs f2 = lin(DFF, 4 * d, p + ".linear2.weight", 0, d, 4 * d, p + ".linear2.bias", Y, d, B * T, ACT_NONE, PREC_F32);
             f2.res = Y; f2.ldr = d;
             ADX_HIP(linear(f2, s));
         }
         ADX_TRY(ln_rows(Y, YN, "ln_f", B * T, RowMap{}, s));
-        ADX_HIP(linear(lin(YN, d, "head.weight", 0, Cout, d, "head.bias", out, Cout, B * T), s));
+        ADX_HIP(linear(lin(YN, d, "head.weight", 0, Cout, d, "head.bias", out, Cout, B * T, ACT_NONE, PREC_F32), s));
         return ADX_OK;
     }
 

@@ -30,6 +30,7 @@ adx_engine::~adx_engine() {
     for (auto& kv : params) {
         if (kv.second.f32) (void)hipFree(kv.second.f32);
         if (kv.second.bf16) (void)hipFree(kv.second.bf16);
+        if (kv.second.bf16lo) (void)hipFree(kv.second.bf16lo);
     }
     if (ws) (void)hipFree(ws);
     if (steps_dev) (void)hipFree(steps_dev);
@@ -53,24 +54,29 @@ const float* adx_engine::P(const std::string& name) const {
     return p ? p->f32 : nullptr;
 }
 
-const void* adx_engine::W(const std::string& name, int64_t row0) const {
+const void* adx_engine::W(const std::string& name, int64_t row0, int prec) const {
     const Param* p = find(name);
     if (!p) return nullptr;
     const int64_t K = p->shape.back();
-    if (cfg.precision == ADX_PREC_BF16) return p->bf16 + row0 * K;
+    if (prec == ADX_PREC_BF16 || prec == ADX_PREC_BF16X3) return p->bf16 + row0 * K;
     return p->f32 + row0 * K;
 }
 
 LinearArgs adx_engine::lin(const float* X, int64_t ldx, const std::string& wname, int64_t row0, int N, int K,
-                           const std::string& bname, float* Y, int64_t ldy, int M, int act) const {
+                           const std::string& bname, float* Y, int64_t ldy, int M, int act, int prec) const {
+    if (prec < 0) prec = cfg.precision;
     LinearArgs a;
     a.X = X; a.ldx = ldx;
-    a.W = W(wname, row0);
+    a.W = W(wname, row0, prec);
+    if (prec == ADX_PREC_BF16X3) {
+        const Param* p = find(wname);
+        a.Wlo = p ? p->bf16lo + row0 * p->shape.back() : nullptr;
+    }
     a.bias = bname.empty() ? nullptr : P(bname) + row0;
     a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K;
     a.act = act;
-    a.prec = cfg.precision;
+    a.prec = prec;
     return a;
 }
 
@@ -87,15 +93,19 @@ int adx_engine::set_tensor(const char* name, const float* data, const int64_t* s
     if (p.numel != numel) {
         if (p.f32) (void)hipFree(p.f32);
         if (p.bf16) (void)hipFree(p.bf16);
-        p.f32 = nullptr; p.bf16 = nullptr;
+        if (p.bf16lo) (void)hipFree(p.bf16lo);
+        p.f32 = nullptr; p.bf16 = nullptr; p.bf16lo = nullptr;
         ADX_HIP(hipMalloc(&p.f32, sizeof(float) * numel));
-        if (ndim >= 2) ADX_HIP(hipMalloc(&p.bf16, sizeof(uint16_t) * numel));
+        if (ndim >= 2) {
+            ADX_HIP(hipMalloc(&p.bf16, sizeof(uint16_t) * numel));
+            ADX_HIP(hipMalloc(&p.bf16lo, sizeof(uint16_t) * numel));
+        }
         drop_graphs();                      // captured graphs hold the old addresses
     }
     p.shape = shp;
     p.numel = numel;
     ADX_HIP(hipMemcpyAsync(p.f32, data, sizeof(float) * numel, hipMemcpyDeviceToDevice, nullptr));
-    if (p.bf16) ADX_HIP(to_bf16(p.f32, p.bf16, numel, nullptr));
+    if (p.bf16) ADX_HIP(to_bf16(p.f32, p.bf16, p.bf16lo, numel, nullptr));
     finalized = false;
     return ADX_OK;
 }
@@ -174,7 +184,7 @@ ADX_API int adx_op_timestep_embedding(const int64_t* t, int n, int dim, float* o
 ADX_API int adx_op_linear(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
                           int prec, void* stream) {
     if (!x || !w || !y) return fail(ADX_EINVAL, "linear: null pointer");
-    if (prec != ADX_PREC_F32 && prec != ADX_PREC_BF16) return fail(ADX_EINVAL, "linear: unknown precision");
+    if (prec != ADX_PREC_F32 && prec != ADX_PREC_BF16) return fail(ADX_EINVAL, "linear: precision must be ADX_PREC_F32 or ADX_PREC_BF16");
     LinearArgs a;
     a.X = x; a.ldx = K; a.W = w; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
     return done(linear(a, (hipStream_t)stream), "linear");
@@ -182,7 +192,7 @@ ADX_API int adx_op_linear(const float* x, const void* w, const float* bias, floa
 
 ADX_API int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
     if (!x || !y) return fail(ADX_EINVAL, "to_bf16: null pointer");
-    return done(to_bf16(x, y, n, (hipStream_t)stream), "to_bf16");
+    return done(to_bf16(x, y, nullptr, n, (hipStream_t)stream), "to_bf16");
 }
 
 ADX_API int adx_op_layernorm(const float* x, const float* gamma, const float* beta, const float* shift, const float* scale,
@@ -229,7 +239,8 @@ ADX_API int adx_op_sched_step(const float* x, const float* model_out, const floa
 
 ADX_API int adx_engine_create(const adx_model_config* cfg, adx_engine** out) {
     if (!cfg || !out) return fail(ADX_EINVAL, "engine_create: null pointer");
-    if (cfg->precision != ADX_PREC_F32 && cfg->precision != ADX_PREC_BF16) return fail(ADX_EINVAL, "engine_create: unknown precision");
+    if (cfg->precision != ADX_PREC_F32 && cfg->precision != ADX_PREC_BF16 && cfg->precision != ADX_PREC_BF16X3)
+        return fail(ADX_EINVAL, "engine_create: unknown precision");
     if (cfg->d_model <= 0 || cfg->n_head <= 0 || cfg->d_model % cfg->n_head) return fail(ADX_EINVAL, "engine_create: d_model must be a positive multiple of n_head");
     if (cfg->horizon <= 0 || cfg->in_dim <= 0 || cfg->out_dim <= 0 || cfg->n_layers <= 0) return fail(ADX_EINVAL, "engine_create: bad dimensions");
     adx_engine* e = nullptr;

@@ -127,11 +127,13 @@ struct EngineDiT final : adx_engine {
     }
 
     // chain of residual-concat stages; input already sits in cat[0][:, :in0]; last fc writes `out` (+ pos)
+    // Stages whose input is raw trajectory coordinates (in <= 8 channels) always run in fp32.
     int run_stages(const std::vector<Stage>& st, std::vector<float*>& cat, int R, float* out, const float* pos, hipStream_t s) {
         for (size_t i = 0; i < st.size(); ++i) {
             const Stage& g = st[i];
             const int ld = g.in + g.hidden;
-            ADX_HIP(linear(lin(cat[i], ld, g.name + ".mlp.linear.weight", 0, g.hidden, g.in, g.name + ".mlp.linear.bias", HT, g.hidden, R), s));
+            const int prec = g.in <= 8 ? (int)PREC_F32 : -1;
+            ADX_HIP(linear(lin(cat[i], ld, g.name + ".mlp.linear.weight", 0, g.hidden, g.in, g.name + ".mlp.linear.bias", HT, g.hidden, R, ACT_NONE, prec), s));
             LayerNormArgs ln;
             ln.x = HT; ln.ldx = g.hidden; ln.y = cat[i] + g.in; ln.ldy = ld;
             ln.gamma = P(g.name + ".mlp.layer_norm.weight"); ln.beta = P(g.name + ".mlp.layer_norm.bias");
@@ -140,7 +142,7 @@ struct EngineDiT final : adx_engine {
             const bool lastst = i + 1 == st.size();
             float* y = lastst ? out : cat[i + 1];
             const int ldy = lastst ? g.out : st[i + 1].in + st[i + 1].hidden;
-            LinearArgs fc = lin(cat[i], ld, g.name + ".fc.weight", 0, g.out, ld, g.name + ".fc.bias", y, ldy, R);
+            LinearArgs fc = lin(cat[i], ld, g.name + ".fc.weight", 0, g.out, ld, g.name + ".fc.bias", y, ldy, R, ACT_NONE, prec);
             if (lastst && pos) { fc.pos = pos; fc.ldp = g.out; fc.pos_period = S; fc.pos_off = 0; }
             ADX_HIP(linear(fc, s));
         }
@@ -256,7 +258,7 @@ struct EngineDiT final : adx_engine {
         // final layer
         ADX_HIP(linear(lin(SIL, d, "final_layer.adaLN_modulation.1.weight", 0, 2 * d, d, "final_layer.adaLN_modulation.1.bias", MODF, 2 * d, R), s));
         ADX_TRY(ln_mod(HX, HN, MODF, 2 * d, 0, R, s));
-        ADX_HIP(linear(lin(HN, d, "final_layer.linear.weight", 0, C, d, "final_layer.linear.bias", out, C, R), s));
+        ADX_HIP(linear(lin(HN, d, "final_layer.linear.weight", 0, C, d, "final_layer.linear.bias", out, C, R, ACT_NONE, PREC_F32), s));
         return ADX_OK;
     }
 

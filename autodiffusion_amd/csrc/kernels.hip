@@ -15,6 +15,8 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_RELU: return v > 0.f ? v : 0.f;
@@ -39,6 +41,8 @@ __device__ __forceinline__ int64_t map_row(const RowMap& r, int m) {
 // K staged through LDS in steps of 32; each of the 4 waves owns a 32x32 sub-tile as 2x2 MFMA tiles.
 //   PREC_F32 : v_mfma_f32_16x16x4_f32 (exact f32 products and sums, k-ordered fma chain)
 //   PREC_BF16: v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 while staged, f32 accumulate)
+//   PREC_BF16X3: the same instruction on split operands x = x_hi + x_lo, w = w_hi + w_lo (three products;
+//              ~16 mantissa bits per operand, i.e. close to f32 results at 3/16 of the f32 MFMA cost)
 // A row's result depends only on that row of X (no split-K, no atomics), so outputs are
 // identical however the batch is sharded over GPUs.
 // ============================================================================================
@@ -48,11 +52,14 @@ constexpr int LDS_BF = BK + 8;    // bf16 per LDS row (80 B)
 
 template <int PREC>
 __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * LDS_F32 * 4];
+    constexpr int SMEM_BYTES = PREC == PREC_BF16X3 ? 4 * BM * LDS_BF * 2 : 2 * BM * LDS_F32 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     float* As = reinterpret_cast<float*>(smem);
     float* Bs = As + BM * LDS_F32;
     unsigned short* Ab = reinterpret_cast<unsigned short*>(smem);
     unsigned short* Bb = Ab + BM * LDS_BF;
+    unsigned short* Al = Bb + BM * LDS_BF;     // low-order halves (PREC_BF16X3 only)
+    unsigned short* Bl = Al + BM * LDS_BF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
     const bool xvec = ((K & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
     const float* Wf = reinterpret_cast<const float*>(a.W);
     const unsigned short* Wb = reinterpret_cast<const unsigned short*>(a.W);
+    const unsigned short* Wl = reinterpret_cast<const unsigned short*>(a.Wlo);
     const bool wvec_f = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
     const bool wvec_b = ((K & 7) == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
     const int br = tid >> 2, bk8 = (tid & 3) * 8;            // bf16 W: row br, 8 k's
@@ -108,6 +116,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
             } else {
                 ushort4 p = make_ushort4(f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w));
                 *reinterpret_cast<ushort4*>(&Ab[r * LDS_BF + akq]) = p;
+                if (PREC == PREC_BF16X3) {
+                    ushort4 q = make_ushort4(f2bf(v.x - bf2f(p.x)), f2bf(v.y - bf2f(p.y)), f2bf(v.z - bf2f(p.z)), f2bf(v.w - bf2f(p.w)));
+                    *reinterpret_cast<ushort4*>(&Al[r * LDS_BF + akq]) = q;
+                }
             }
         }
         // ---- stage W tile
@@ -145,6 +157,22 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
                 }
             }
             *reinterpret_cast<uint4*>(&Bb[br * LDS_BF + bk8]) = v;
+            if (PREC == PREC_BF16X3) {
+                uint4 u = make_uint4(0u, 0u, 0u, 0u);
+                if (n < N) {
+                    const unsigned short* w = Wl + (int64_t)n * K;
+                    if (wvec_b && k + 7 < K) {
+                        u = *reinterpret_cast<const uint4*>(w + k);
+                    } else {
+                        unsigned short e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) e[j] = (k + j < K) ? w[k + j] : (unsigned short)0;
+                        u.x = e[0] | ((unsigned)e[1] << 16); u.y = e[2] | ((unsigned)e[3] << 16);
+                        u.z = e[4] | ((unsigned)e[5] << 16); u.w = e[6] | ((unsigned)e[7] << 16);
+                    }
+                }
+                *reinterpret_cast<uint4*>(&Bl[br * LDS_BF + bk8]) = u;
+            }
         }
         __syncthreads();
         // ---- MFMA over the staged K step
@@ -173,6 +201,22 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
             for (int i = 0; i < 2; ++i) {
                 af[i] = *reinterpret_cast<const bf16x8*>(&Ab[(wr * 32 + i * 16 + (lane & 15)) * LDS_BF + 8 * (lane >> 4)]);
                 bfr[i] = *reinterpret_cast<const bf16x8*>(&Bb[(wc * 32 + i * 16 + (lane & 15)) * LDS_BF + 8 * (lane >> 4)]);
+            }
+            if (PREC == PREC_BF16X3) {
+                // x w ~= x_lo w_hi + x_hi w_lo + x_hi w_hi  (the two small cross terms first)
+                bf16x8 al[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    al[i] = *reinterpret_cast<const bf16x8*>(&Al[(wr * 32 + i * 16 + (lane & 15)) * LDS_BF + 8 * (lane >> 4)]);
+                    bl[i] = *reinterpret_cast<const bf16x8*>(&Bl[(wc * 32 + i * 16 + (lane & 15)) * LDS_BF + 8 * (lane >> 4)]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -212,7 +256,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
 hipError_t linear(const LinearArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
-    if (a.prec == PREC_BF16)
+    if (a.prec == PREC_BF16X3) {
+        if (!a.Wlo) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(linear_kernel<PREC_BF16X3>, grid, dim3(256), 0, stream, a);
+    } else if (a.prec == PREC_BF16)
         hipLaunchKernelGGL(linear_kernel<PREC_BF16>, grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(linear_kernel<PREC_F32>, grid, dim3(256), 0, stream, a);
@@ -579,15 +626,20 @@ hipError_t sched_step(const float* x, const float* model_out, const float* z, fl
     return hipGetLastError();
 }
 
-__global__ void to_bf16_kernel(const float* x, uint16_t* y, int64_t n) {
+__global__ void to_bf16_kernel(const float* x, uint16_t* y, uint16_t* ylo, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) y[i] = f2bf(x[i]);
+    for (; i < n; i += stride) {
+        const float v = x[i];
+        const unsigned short h = f2bf(v);
+        y[i] = h;
+        if (ylo) ylo[i] = f2bf(v - bf2f(h));
+    }
 }
 
-hipError_t to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream) {
+hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream) {
     if (n <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, ylo, n);
     return hipGetLastError();
 }
 

@@ -148,7 +148,7 @@ class Transformer_TrajDiffusionModel(nn.Module):
             c = self.config
             self._engine = Engine(
                 variant=_lib.VARIANT_DIT if c.diffusion_backbone == "DiT" else _lib.VARIANT_MMDIT,
-                precision={"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[self.precision], elide=0,
+                precision=_lib.PRECISIONS[self.precision], elide=0,
                 d_model=c.n_embd, n_head=c.n_head, n_enc_layers=0, n_layers=c.n_layer, horizon=self.predict_range,
                 in_dim=self.out_features, out_dim=self.out_features, n_inner=c.n_inner, connect_dim=self.connect_dim)
             self._engine_key = key

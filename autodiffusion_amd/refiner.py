@@ -146,7 +146,7 @@ class Transformer(nn.Module):
     def engine(self) -> Engine:
         key = (self.precision, self.elide)
         if self._engine is None or self._engine_key != key:
-            prec = {"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[self.precision]
+            prec = _lib.PRECISIONS[self.precision]
             if self._engine is not None:
                 self._engine.close()
             self._engine = Engine(variant=_lib.VARIANT_A, precision=prec, elide=int(self.elide), **self._dims)

@@ -62,6 +62,28 @@ def fill_module_(module: torch.nn.Module, seed: int) -> torch.nn.Module:
     return module
 
 
+def reference_init_(module: torch.nn.Module, seed: int) -> torch.nn.Module:
+    """Random initialisation in the style the reference applies to its refiner
+    (transformer4planning/models/diffusion_loss/transformer.py:149-187): every matrix and
+    positional table ~ N(0, 0.02), biases 0, LayerNorm gains 1; a 2-D ``init_x`` ~ N(0, 1)
+    (DiffusionAugmentation.py:70-71).  Seeded per parameter name.
+    """
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            x = _rng(seed, n).standard_normal(size=tuple(p.shape)).astype(np.float32)
+            leaf = n.split(".")
+            if leaf[-1] == "init_x":
+                pass
+            elif p.dim() >= 2:
+                x *= np.float32(0.02)
+            elif leaf[-1] == "weight" and any(k in leaf[-2] for k in ("norm", "ln_f", "layer_norm")):
+                x = np.ones_like(x)
+            else:
+                x = np.zeros_like(x)
+            p.copy_(torch.from_numpy(x).to(p.dtype))
+    return module
+
+
 def _rows(seed: int, tag: str, row0: int, nrows: int, tail: Tuple[int, ...]) -> np.ndarray:
     """Standard-normal block whose row r only depends on (seed, tag, global row r)."""
     out = np.empty((nrows,) + tail, dtype=np.float32)

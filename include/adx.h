@@ -30,7 +30,9 @@ extern "C" {
 enum { ADX_OK = 0, ADX_EINVAL = 1, ADX_ESTATE = 2, ADX_EHIP = 3, ADX_ENOMEM = 4, ADX_ENOTFOUND = 5 };
 
 enum { ADX_ACT_NONE = 0, ADX_ACT_RELU = 1, ADX_ACT_GELU_ERF = 2, ADX_ACT_GELU_TANH = 3, ADX_ACT_LEAKY = 4, ADX_ACT_SILU = 5 };
-enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1 };   /* GEMM operand type; accumulation is always f32 */
+/* GEMM operand type; accumulation is always f32.  BF16X3 (engines only): bf16 MFMA on operands split into
+ * high + low bf16 halves (x_lo w_hi + x_hi w_lo + x_hi w_hi), ~16 mantissa bits per operand. */
+enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1, ADX_PREC_BF16X3 = 2 };
 enum { ADX_VARIANT_A = 0, ADX_VARIANT_DIT = 1, ADX_VARIANT_MMDIT = 2 };
 
 /* sampling flags */
