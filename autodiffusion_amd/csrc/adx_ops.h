@@ -62,8 +62,24 @@ struct AttentionArgs {
     int B = 0, H = 0, Sq = 0, Skv = 0, dh = 0, dv = 0;
     float scale = 1.f;
     int mask_off = -1;
+    // Small-head kernels only.  state != nullptr: instead of O, store the running softmax state of every query,
+    // {m, l, o[dh]} per (query, head) with m in log2 units of the scaled score and o un-normalised; row stride
+    // state_ld floats (= H * (2 + dh)).  key0 != nullptr: key/value 0 of EVERY batch item are read from
+    // key0[0:H*dh] / key0[H*dh:2*H*dh] instead of K/V (the per-step time token).
+    float* state = nullptr; int64_t state_ld = 0; int64_t state_batch_stride = 0;
+    const float* key0 = nullptr;
 };
 hipError_t attention(const AttentionArgs& a, hipStream_t stream);
+
+// Attention of a FEW queries (Sq <= 16 per launch group) against many keys, head_dim 4: one workgroup per
+// (batch item, group of NQ queries), all heads; keys are spread over the threads and the per-thread softmax
+// states are merged by shuffles and one LDS pass.  Honors a.key0; no mask.
+hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream);
+
+// Fold ONE extra key (the time token: key0 = [k(H*dh), v(H*dh)], shared by all batch items) into cached softmax
+// states: O[b, r, h, :] = (o * 2^(m - m') + 2^(s - m') v) / (l * 2^(m - m') + 2^(s - m')),  s = scale*log2e*<q, k>.
+// Q/O/state address rows exactly as in AttentionArgs (Sq rows per batch item).  head_dim 4.
+hipError_t attention_merge_key(const AttentionArgs& a, hipStream_t stream);
 
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
 hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);

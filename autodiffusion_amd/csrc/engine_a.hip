@@ -32,6 +32,13 @@ struct EngineA final : adx_engine {
     float *Y = nullptr, *YN = nullptr, *DQKV = nullptr, *DATT = nullptr, *DFF = nullptr, *MKV = nullptr, *DQ = nullptr;
     float *XS0 = nullptr, *XS1 = nullptr, *MOUT = nullptr, *TRAN = nullptr, *PRIN = nullptr, *TRAW = nullptr, *PRAW = nullptr,
           *CHO = nullptr, *TE = nullptr;
+    // elide level 2: layer-0 attention cache.  QKV0: in_proj(LN1(X0)) of every conditioning row, valid for a whole chunk
+    // (rows >= 1 do not depend on the diffusion step); ST: softmax state of every query row >= 1 over key rows >= 1;
+    // tqkv0: per-step q/k/v of the time token (identical for every batch item), [n_steps][3d].
+    float *QKV0 = nullptr, *ST = nullptr, *tqkv0 = nullptr;
+    bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
+
+    ~EngineA() override { if (tqkv0) (void)hipFree(tqkv0); }
 
     explicit EngineA(const adx_model_config& c) {
         cfg = c;
@@ -40,6 +47,8 @@ struct EngineA final : adx_engine {
         n_enc = c.n_enc_layers; n_dec = c.n_layers;
         L = 1 + nmaps + 2 * NP;
         Lm = c.elide ? T + 1 : L;
+        fast4 = (H == 8 && d == 32);
+        if (cfg.elide >= 2 && !fast4) cfg.elide = 1;
     }
 
     std::vector<ParamSpec> expected_params() const override {
@@ -87,12 +96,48 @@ struct EngineA final : adx_engine {
         take(&TRAN, (size_t)B * NP * Cp); take(&PRIN, (size_t)B * NP * Cp);
         take(&TRAW, (size_t)B * NP * Cp); take(&PRAW, (size_t)B * NP * Cp); take(&CHO, BT * Cin);
         take(&TE, (size_t)B * d);
+        if (cfg.elide >= 2) { take(&QKV0, BL * 3 * d); take(&ST, BL * H * 6); }
         *bytes = off;
         return ADX_OK;
     }
 
     int build_time_table(hipStream_t s) override {
-        ADX_HIP(timestep_embedding(steps_t_dev, (int)steps.size(), d, temb_table, d, s));
+        const int n = (int)steps.size();
+        ADX_HIP(timestep_embedding(steps_t_dev, n, d, temb_table, d, s));
+        if (cfg.elide >= 2) {
+            // q/k/v of the time token under encoder layer 0, one row per step
+            if (tqkv0) (void)hipFree(tqkv0);
+            tqkv0 = nullptr;
+            float* tmp = nullptr;
+            ADX_HIP(hipMalloc(&tqkv0, sizeof(float) * (size_t)n * 3 * d));
+            ADX_HIP(hipMalloc(&tmp, sizeof(float) * (size_t)n * d));
+            const std::string p = "encoder.layers.0";
+            hipError_t e = add_vec_act(temb_table, P("cond_pos_emb"), tmp, n, d, 0, ACT_NONE, s);
+            int rc = ADX_OK;
+            if (e == hipSuccess) rc = ln_rows(tmp, tmp, p + ".norm1", n, RowMap{}, s);
+            if (e == hipSuccess && rc == ADX_OK)
+                e = linear(lin(tmp, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", tqkv0, 3 * d, n), s);
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return hip_fail(e, "build_time_table");
+            return rc;
+        }
+        return ADX_OK;
+    }
+
+    // Per chunk: q/k/v of all conditioning rows under layer 0 and the softmax state of rows >= 1 over keys >= 1.
+    int build_chunk_cache(int B, hipStream_t s) {
+        const std::string p = "encoder.layers.0";
+        const int dh = d / H;
+        ADX_TRY(ln_rows(X0, H1, p + ".norm1", B * L, RowMap{}, s));
+        ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV0, 3 * d, B * L), s));
+        AttentionArgs at;
+        at.Q = QKV0 + 3 * d; at.K = QKV0 + 3 * d + d; at.V = QKV0 + 3 * d + 2 * d;
+        at.ldq = at.ldk = at.ldv = 3 * d;
+        at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)L * 3 * d;
+        at.B = B; at.H = H; at.Sq = L - 1; at.Skv = L - 1; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
+        at.state = ST + H * 6; at.state_ld = H * 6; at.state_batch_stride = (int64_t)L * H * 6;
+        ADX_HIP(attention(at, s));
         return ADX_OK;
     }
 
@@ -133,7 +178,8 @@ struct EngineA final : adx_engine {
 
     // ---------------------------------------------------------------------------------- the network
     // X0 must hold the conditioning rows; x is (B,T,Cin); out is (B,T,Cout).
-    int run_net(int B, const float* x, float* out, hipStream_t s) {
+    // step >= 0 selects the cached layer-0 attention of elide level 2 (row `step` of tqkv0).
+    int run_net(int B, const float* x, float* out, hipStream_t s, int step = -1) {
         const int dh = d / H;
         const float scale = 1.0f / sqrtf((float)dh);
         const float* cur = X0;
@@ -144,6 +190,22 @@ struct EngineA final : adx_engine {
             const bool last = cfg.elide && i == n_enc - 1;
             const int rq = last ? T + 1 : L;                      // query rows per batch item
             const RowMap qmap = last ? RowMap{rq, L, 0} : RowMap{};
+            if (i == 0 && step >= 0 && !last) {
+                // layer-0 attention from the chunk cache: only the time token (row 0) changed since the cache was built
+                const float* tq = tqkv0 + (int64_t)step * 3 * d;
+                AttentionArgs a0;
+                a0.Q = tq; a0.ldq = 3 * d; a0.q_batch_stride = 0;
+                a0.K = QKV0 + d; a0.V = QKV0 + 2 * d; a0.ldk = a0.ldv = 3 * d; a0.k_batch_stride = a0.v_batch_stride = (int64_t)L * 3 * d;
+                a0.O = ATT; a0.ldo = d; a0.o_batch_stride = (int64_t)L * d;
+                a0.B = B; a0.H = H; a0.Sq = 1; a0.Skv = L; a0.dh = dh; a0.dv = dh; a0.scale = scale; a0.key0 = tq + d;
+                ADX_HIP(attention_few_queries(a0, s));
+                AttentionArgs a1;
+                a1.Q = QKV0 + 3 * d; a1.ldq = 3 * d; a1.q_batch_stride = (int64_t)L * 3 * d;
+                a1.O = ATT + d; a1.ldo = d; a1.o_batch_stride = (int64_t)L * d;
+                a1.B = B; a1.H = H; a1.Sq = L - 1; a1.dh = dh; a1.dv = dh; a1.scale = scale; a1.key0 = tq + d;
+                a1.state = ST + H * 6; a1.state_ld = H * 6; a1.state_batch_stride = (int64_t)L * H * 6;
+                ADX_HIP(attention_merge_key(a1, s));
+            } else {
             ADX_TRY(ln_rows(cur, H1, p + ".norm1", B * L, RowMap{}, s));
             if (!last) {
                 ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * L), s));
@@ -160,7 +222,9 @@ struct EngineA final : adx_engine {
             at.V = QKV + 2 * d; at.ldv = 3 * d; at.v_batch_stride = (int64_t)L * 3 * d;
             at.O = ATT; at.ldo = d; at.o_batch_stride = (int64_t)L * d;
             at.B = B; at.H = H; at.Sq = rq; at.Skv = L; at.dh = dh; at.dv = dh; at.scale = scale; at.mask_off = -1;
-            ADX_HIP(attention(at, s));
+            if (last && fast4) ADX_HIP(attention_few_queries(at, s));
+            else ADX_HIP(attention(at, s));
+            }
             LinearArgs o = lin(ATT, d, p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias", nxt, d, B * rq);
             o.xmap = qmap; o.ymap = qmap; o.res = cur; o.ldr = d;
             ADX_HIP(linear(o, s));
@@ -252,12 +316,17 @@ struct EngineA final : adx_engine {
             tn = TRAN; pn = PRIN;
         }
         ADX_TRY(embed_prior(B, tn, pn, s));
+        const bool cached = cfg.elide >= 2 && n_enc >= 2;
+        if (cached) {
+            ADX_TRY(set_time(B, temb_table, 0, s));          // defined (if irrelevant) values in row 0 before the cache pass
+            ADX_TRY(build_chunk_cache(B, s));
+        }
         float* xc = XS0; float* xn = XS1;
         if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, s));
         else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, s));
         for (size_t k = 0; k < steps.size(); ++k) {
             ADX_TRY(set_time(B, temb_table + k * d, 0, s));
-            ADX_TRY(run_net(B, xc, MOUT, s));
+            ADX_TRY(run_net(B, xc, MOUT, s, cached ? (int)k : -1));
             if (trace_x) ADX_HIP(copy2d(xc, n, 0, trace_x + k * n, n, 1, (int)n, s));
             if (trace_out) ADX_HIP(copy2d(MOUT, n, 0, trace_out + k * n, n, 1, (int)n, s));
             const int zi = (int)steps[k].z_index;

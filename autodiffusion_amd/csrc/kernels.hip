@@ -370,11 +370,143 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttentionArgs a) 
         }
     }
     if (qok) {
-        float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + h * DH;
-        const float inv = 1.f / l;
+        if (a.state) {
+            float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)q * a.state_ld + h * (2 + DH);
+            Sp[0] = m; Sp[1] = l;
 #pragma unroll
-        for (int c = 0; c < DH; ++c) Op[c] = o[c] * inv;
+            for (int c = 0; c < DH; ++c) Sp[2 + c] = o[c];
+        } else {
+            float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + h * DH;
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) Op[c] = o[c] * inv;
+        }
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// Few queries x many keys, head_dim 4.  256 threads = 8 heads x 32 key lanes (heads fastest, so a wave reads
+// whole 128-B key rows); every thread keeps NQ softmax states in registers.
+// --------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
+    constexpr int DH = 4;
+    __shared__ float red[4][8][NQ][2 + DH];
+    const int b = blockIdx.y, q0 = blockIdx.x * NQ;
+    const int tid = threadIdx.x, h = tid & 7, kl = tid >> 3;       // requires H == 8
+    const int lane = tid & 63, wave = tid >> 6;
+    float qv[NQ][DH], m[NQ], l[NQ], o[NQ][DH];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = min(q0 + i, a.Sq - 1);
+        const float4 t = *reinterpret_cast<const float4*>(a.Q + (int64_t)b * a.q_batch_stride + (int64_t)q * a.ldq + h * DH);
+        const float f = a.scale * LOG2E;
+        qv[i][0] = t.x * f; qv[i][1] = t.y * f; qv[i][2] = t.z * f; qv[i][3] = t.w * f;
+        m[i] = -INFINITY; l[i] = 0.f;
+        o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
+    }
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + h * DH;
+    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + h * DH;
+    for (int j = kl; j < a.Skv; j += 32) {
+        float4 kk, vv;
+        if (j == 0 && a.key0) {
+            kk = *reinterpret_cast<const float4*>(a.key0 + h * DH);
+            vv = *reinterpret_cast<const float4*>(a.key0 + a.H * DH + h * DH);
+        } else {
+            kk = *reinterpret_cast<const float4*>(Kb + (int64_t)j * a.ldk);
+            vv = *reinterpret_cast<const float4*>(Vb + (int64_t)j * a.ldv);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
+            const float mn = fmaxf(m[i], s);
+            const float al = exp2f(m[i] - mn), p = exp2f(s - mn);
+            l[i] = fmaf(l[i], al, p);
+            o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
+            o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
+            m[i] = mn;
+        }
+    }
+    // merge the 8 key lanes of a wave (lanes with equal h are 8 apart)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[i], off, 64), l2 = __shfl_xor(l[i], off, 64);
+            const float o0 = __shfl_xor(o[i][0], off, 64), o1 = __shfl_xor(o[i][1], off, 64);
+            const float o2 = __shfl_xor(o[i][2], off, 64), o3 = __shfl_xor(o[i][3], off, 64);
+            const float mn = fmaxf(m[i], m2);
+            const float a1 = mn == -INFINITY ? 0.f : exp2f(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2f(m2 - mn);
+            l[i] = l[i] * a1 + l2 * a2;
+            o[i][0] = o[i][0] * a1 + o0 * a2; o[i][1] = o[i][1] * a1 + o1 * a2;
+            o[i][2] = o[i][2] * a1 + o2 * a2; o[i][3] = o[i][3] * a1 + o3 * a2;
+            m[i] = mn;
+        }
+        if (lane < 8) {
+            float* r = red[wave][lane][i];
+            r[0] = m[i]; r[1] = l[i]; r[2] = o[i][0]; r[3] = o[i][1]; r[4] = o[i][2]; r[5] = o[i][3];
+        }
+    }
+    __syncthreads();
+    // final merge of the 4 waves: one thread per (head, query)
+    if (tid < 8 * NQ) {
+        const int hh = tid & 7, i = tid >> 3;
+        if (q0 + i < a.Sq) {
+            float mn = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) mn = fmaxf(mn, red[w][hh][i][0]);
+            float ls = 0.f, os[DH] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* r = red[w][hh][i];
+                const float al = r[0] == -INFINITY ? 0.f : exp2f(r[0] - mn);
+                ls += r[1] * al;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) os[c] += r[2 + c] * al;
+            }
+            const float inv = 1.f / ls;
+            float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)(q0 + i) * a.ldo + hh * DH;
+            *reinterpret_cast<float4*>(Op) = make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
+        }
+    }
+}
+
+hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.H != 8 || a.dh != 4 || a.dv != 4 || a.mask_off >= 0) return hipErrorInvalidValue;
+    if (a.Sq == 1) hipLaunchKernelGGL(attn_fewq_kernel<1>, dim3(1, a.B), dim3(256), 0, stream, a);
+    else if (a.Sq <= 4) hipLaunchKernelGGL(attn_fewq_kernel<4>, dim3(1, a.B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_fewq_kernel<12>, dim3((a.Sq + 11) / 12, a.B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// One thread per (row, head); heads fastest so that a wave touches whole rows of Q, state and O.
+__global__ __launch_bounds__(256) void attn_merge_key_kernel(const AttentionArgs a) {
+    constexpr int DH = 4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)a.B * a.Sq * a.H;
+    if (idx >= total) return;
+    const int h = (int)(idx % a.H);
+    const int64_t row = idx / a.H;
+    const int b = (int)(row / a.Sq), r = (int)(row % a.Sq);
+    const float4 q = *reinterpret_cast<const float4*>(a.Q + (int64_t)b * a.q_batch_stride + (int64_t)r * a.ldq + h * DH);
+    const float4 k = *reinterpret_cast<const float4*>(a.key0 + h * DH);
+    const float4 v = *reinterpret_cast<const float4*>(a.key0 + a.H * DH + h * DH);
+    const float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)r * a.state_ld + h * (2 + DH);
+    const float m = Sp[0], l = Sp[1];
+    const float s = (q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w) * (a.scale * LOG2E);
+    const float mn = fmaxf(m, s);
+    const float al = exp2f(m - mn), p = exp2f(s - mn);
+    const float inv = 1.f / fmaf(l, al, p);
+    float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)r * a.ldo + h * DH;
+    *reinterpret_cast<float4*>(Op) = make_float4(fmaf(Sp[2], al, p * v.x) * inv, fmaf(Sp[3], al, p * v.y) * inv,
+                                                 fmaf(Sp[4], al, p * v.z) * inv, fmaf(Sp[5], al, p * v.w) * inv);
+}
+
+hipError_t attention_merge_key(const AttentionArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.Sq <= 0 || a.H <= 0 || a.dh != 4 || !a.state || !a.key0) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)a.B * a.Sq * a.H;
+    hipLaunchKernelGGL(attn_merge_key_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 // ============================================================================================

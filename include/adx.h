@@ -100,7 +100,9 @@ typedef struct adx_engine adx_engine;
 typedef struct adx_model_config {
     int variant;        /* ADX_VARIANT_* */
     int precision;      /* ADX_PREC_* */
-    int elide;          /* 1: skip work whose result the masks make unobservable (exact in real arithmetic) */
+    int elide;          /* 0: every op of the reference; 1: skip work whose result the masks make unobservable;
+                           2: also reuse, within a chunk, the encoder layer-0 attention of all step-invariant rows
+                              (both exact in real arithmetic; 2 re-associates one softmax sum) */
     int d_model;        /* n_emb (A) / feat_dim = n_embd (DiT) */
     int n_head;
     int n_enc_layers;   /* A: n_cond_layers */
