@@ -81,6 +81,29 @@ hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream);
 // Q/O/state address rows exactly as in AttentionArgs (Sq rows per batch item).  head_dim 4.
 hipError_t attention_merge_key(const AttentionArgs& a, hipStream_t stream);
 
+// Fused per-row pipeline of the variant-A encoder (d_model 32, 8 heads, FFN 128); see fused_a.hip.
+// For every conditioning row: fold the time-token key (key0 = [k(32), v(32)]) into the cached layer-0 softmax state
+// (row 0 of each item takes its attention output from att0 instead), out_proj + residual, LayerNorm, FFN + residual,
+// then layer 1's LayerNorm and K/V projection.  Rows r < n_keep of every item also store the layer-1 residual input
+// (x1) and its normalised copy (h1).
+struct EncRowsArgs {
+    const float* x0 = nullptr;                       // [B*L][32] encoder input rows
+    const float* q = nullptr; int64_t ldq = 0;       // layer-0 queries, row stride ldq
+    const float* state = nullptr;                    // [B*L][8][6] {m, l, o[4]}
+    const float* att0 = nullptr;                     // [B*L][32], only row 0 of each item is read
+    const float* key0 = nullptr;                     // [64]
+    const void* image = nullptr;                     // weight fragment image from enc_rows_build_image
+    const float* img_f32 = nullptr; const unsigned short* img_bf = nullptr;   // filled by the launcher
+    const float* vecs = nullptr;                     // [384] bo, gamma2, beta2, b2, gamma1', beta1', b1(128), bkv(64)
+    float* kv = nullptr; int64_t ldkv = 0;           // K at kv[row*ldkv + 0..31], V at +32..63
+    float* x1 = nullptr; float* h1 = nullptr;        // [B*L][32]
+    int B = 0, L = 0, n_keep = 0;
+    float scale = 1.f;
+};
+size_t enc_rows_image_bytes();
+hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, void* image, hipStream_t stream);
+hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);
+
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
 hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);
 

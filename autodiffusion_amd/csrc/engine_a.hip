@@ -37,8 +37,16 @@ struct EngineA final : adx_engine {
     // tqkv0: per-step q/k/v of the time token (identical for every batch item), [n_steps][3d].
     float *QKV0 = nullptr, *ST = nullptr, *tqkv0 = nullptr;
     bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
+    // elide level 3: the per-row pipeline between the two encoder attentions runs as one fused kernel
+    bool fused = false;
+    void* rows_image = nullptr;
+    float* rows_vecs = nullptr;
 
-    ~EngineA() override { if (tqkv0) (void)hipFree(tqkv0); }
+    ~EngineA() override {
+        if (tqkv0) (void)hipFree(tqkv0);
+        if (rows_image) (void)hipFree(rows_image);
+        if (rows_vecs) (void)hipFree(rows_vecs);
+    }
 
     explicit EngineA(const adx_model_config& c) {
         cfg = c;
@@ -49,6 +57,7 @@ struct EngineA final : adx_engine {
         Lm = c.elide ? T + 1 : L;
         fast4 = (H == 8 && d == 32);
         if (cfg.elide >= 2 && !fast4) cfg.elide = 1;
+        fused = cfg.elide >= 3 && n_enc == 2;
     }
 
     std::vector<ParamSpec> expected_params() const override {
@@ -120,7 +129,21 @@ struct EngineA final : adx_engine {
             (void)hipStreamSynchronize(s);
             (void)hipFree(tmp);
             if (e != hipSuccess) return hip_fail(e, "build_time_table");
-            return rc;
+            if (rc != ADX_OK) return rc;
+        }
+        if (fused) {
+            if (!rows_image) ADX_HIP(hipMalloc(&rows_image, enc_rows_image_bytes()));
+            if (!rows_vecs) ADX_HIP(hipMalloc(&rows_vecs, sizeof(float) * 384));
+            const std::string p0 = "encoder.layers.0", p1 = "encoder.layers.1";
+            ADX_HIP(enc_rows_build_image(P(p0 + ".self_attn.out_proj.weight"), P(p0 + ".linear1.weight"), P(p0 + ".linear2.weight"),
+                                         P(p1 + ".self_attn.in_proj_weight") + (int64_t)d * d, rows_image, s));
+            struct { const float* src; int off, n; } parts[] = {
+                {P(p0 + ".self_attn.out_proj.bias"), 0, 32}, {P(p0 + ".norm2.weight"), 32, 32}, {P(p0 + ".norm2.bias"), 64, 32},
+                {P(p0 + ".linear2.bias"), 96, 32}, {P(p1 + ".norm1.weight"), 128, 32}, {P(p1 + ".norm1.bias"), 160, 32},
+                {P(p0 + ".linear1.bias"), 192, 128}, {P(p1 + ".self_attn.in_proj_bias") + d, 320, 64}};
+            for (const auto& q : parts)
+                ADX_HIP(hipMemcpyAsync(rows_vecs + q.off, q.src, sizeof(float) * q.n, hipMemcpyDeviceToDevice, s));
+            ADX_HIP(hipStreamSynchronize(s));
         }
         return ADX_OK;
     }
@@ -183,8 +206,29 @@ struct EngineA final : adx_engine {
         const int dh = d / H;
         const float scale = 1.0f / sqrtf((float)dh);
         const float* cur = X0;
+        int first_layer = 0;
+        bool kv_done = false;
+        if (step >= 0 && fused) {
+            // layer 0 + layer 1's LayerNorm and K/V projection in two launches
+            const float* tq = tqkv0 + (int64_t)step * 3 * d;
+            AttentionArgs a0;
+            a0.Q = tq; a0.ldq = 3 * d; a0.q_batch_stride = 0;
+            a0.K = QKV0 + d; a0.V = QKV0 + 2 * d; a0.ldk = a0.ldv = 3 * d; a0.k_batch_stride = a0.v_batch_stride = (int64_t)L * 3 * d;
+            a0.O = ATT; a0.ldo = d; a0.o_batch_stride = (int64_t)L * d;
+            a0.B = B; a0.H = H; a0.Sq = 1; a0.Skv = L; a0.dh = dh; a0.dv = dh; a0.scale = scale; a0.key0 = tq + d;
+            ADX_HIP(attention_few_queries(a0, s));
+            EncRowsArgs r;
+            r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.att0 = ATT; r.key0 = tq + d;
+            r.image = rows_image; r.vecs = rows_vecs;
+            r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.h1 = H1;
+            r.B = B; r.L = L; r.n_keep = T + 1; r.scale = scale;
+            ADX_HIP(enc_rows(r, cfg.precision, s));
+            cur = XA;
+            first_layer = 1;
+            kv_done = true;
+        }
         // ---- encoder (pre-norm, GELU)
-        for (int i = 0; i < n_enc; ++i) {
+        for (int i = first_layer; i < n_enc; ++i) {
             const std::string p = "encoder.layers." + std::to_string(i);
             float* nxt = (i & 1) ? XB : XA;
             const bool last = cfg.elide && i == n_enc - 1;
@@ -206,12 +250,14 @@ struct EngineA final : adx_engine {
                 a1.state = ST + H * 6; a1.state_ld = H * 6; a1.state_batch_stride = (int64_t)L * H * 6;
                 ADX_HIP(attention_merge_key(a1, s));
             } else {
-            ADX_TRY(ln_rows(cur, H1, p + ".norm1", B * L, RowMap{}, s));
+            if (!(last && kv_done)) ADX_TRY(ln_rows(cur, H1, p + ".norm1", B * L, RowMap{}, s));
             if (!last) {
                 ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * L), s));
             } else {
-                LinearArgs kv = lin(H1, d, p + ".self_attn.in_proj_weight", d, 2 * d, d, p + ".self_attn.in_proj_bias", QKV + d, 3 * d, B * L);
-                ADX_HIP(linear(kv, s));
+                if (!kv_done) {
+                    LinearArgs kv = lin(H1, d, p + ".self_attn.in_proj_weight", d, 2 * d, d, p + ".self_attn.in_proj_bias", QKV + d, 3 * d, B * L);
+                    ADX_HIP(linear(kv, s));
+                }
                 LinearArgs q = lin(H1, d, p + ".self_attn.in_proj_weight", 0, d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * rq);
                 q.xmap = qmap; q.ymap = qmap;
                 ADX_HIP(linear(q, s));

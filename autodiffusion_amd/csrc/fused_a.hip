@@ -1,0 +1,311 @@
+// Fused per-row pipeline of the variant-A conditioning encoder (d_model 32, 8 heads, FFN 128), gfx950.
+//
+// One launch per diffusion step replaces, for all B*L conditioning rows:
+//     layer 0:  fold the time-token key into the cached softmax state  ->  out_proj + residual  ->  LayerNorm
+//               ->  FFN (GELU)  + residual
+//     layer 1:  LayerNorm  ->  K/V projection
+// Rows are independent, so every wavefront owns a tile of 32 rows and keeps the whole chain in registers.
+//
+// Layout.  All products are computed TRANSPOSED, Y^T = W X^T, with v_mfma 32x32: the weight tile is the A operand
+// (32 output features x k), the activations are the B operand (k x 32 rows).  The accumulator of a 32x32 MFMA holds,
+// in lane l (c = l & 31, h = l >> 5) and register reg, feature  f(reg, h) = (reg & 3) + 8 (reg >> 2) + 4 h  of row c.
+// An accumulator is therefore already "k on registers, row on the lane" and feeds the next product as B operand with
+// no data movement:
+//   * PREC_F32   : v_mfma_f32_32x32x2_f32, one instruction per register (k pair = features f(reg,0), f(reg,1));
+//   * PREC_BF16X3: v_mfma_f32_32x32x16_bf16 on registers 8s..8s+7 converted to bf16 (k order inside the step is
+//                  16s + 8 (j >> 2) + 4h + (j & 3)); operands split in high + low halves, three products.
+// The weight fragments are pre-arranged in exactly that k order by build_image_kernel and staged in LDS once per
+// workgroup.  LayerNorm reduces 16 registers in-lane plus one exchange with lane l ^ 32.
+//
+// HBM traffic per row and step (f32): read x0 128 B, q 128 B, softmax state 192 B; write k/v 256 B  -> 704 B.
+#include "adx_ops.h"
+
+#include <math.h>
+
+namespace adx {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+namespace {
+
+constexpr int D = 32, FF = 128, NH = 8;
+constexpr float LOG2E_F = 1.4426950408889634f;
+
+// ---- fragment image -------------------------------------------------------------------------------------------
+// matrices in image order: Wo (32x32), W1 (128x32), W2 (32x128), Wkv (64x32)
+// F32   : fragment (mat, nt, it, reg)  = 64 floats: lane l -> W[32 nt + (l & 31)][32 it + f(reg, l >> 5)]
+// BF16X3: fragment (mat, nt, it, s)    = 64 lanes x 8 bf16 (hi image, then lo image)
+constexpr int NFRAG_F32 = 16 * (1 + 4 + 4 + 2);          // 176 fragments of 256 B
+constexpr int NFRAG_BF = 2 * (1 + 4 + 4 + 2);            // 22 fragments of 1 KiB per half
+constexpr int IMG_F32_FLOATS = NFRAG_F32 * 64;           // 11264 floats = 45056 B
+constexpr int IMG_BF_SHORTS = 2 * NFRAG_BF * 64 * 8;     // hi + lo: 22528 shorts = 45056 B
+constexpr int VEC_FLOATS = 32 * 6 + 128 + 64;            // bo g2 be2 b2 g1 be1 (6 x 32) + b1 (128) + bkv (64) = 384
+
+// base fragment index of each matrix (in units of "nt, it" tiles)
+__host__ __device__ constexpr int tile_base(int mat) { return mat == 0 ? 0 : (mat == 1 ? 1 : (mat == 2 ? 5 : 9)); }
+// number of input tiles (K / 32) of each matrix
+__host__ __device__ constexpr int in_tiles(int mat) { return mat == 2 ? 4 : 1; }
+
+__device__ __forceinline__ int feat(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ unsigned short f2bf_(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f_(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+struct ImageSrc {
+    const float* W[4];   // Wo [32][32], W1 [128][32], W2 [32][128], Wkv [64][32]
+};
+
+__global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short* img_bf) {
+    const int nt_count[4] = {1, 4, 1, 2};
+    const int Kdim[4] = {32, 32, 128, 32};
+    int tile = 0;
+    for (int mat = 0; mat < 4; ++mat)
+        for (int nt = 0; nt < nt_count[mat]; ++nt)
+            for (int it = 0; it < in_tiles(mat); ++it, ++tile) {
+                for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 16 * 64; e += gridDim.x * blockDim.x) {
+                    const int reg = e >> 6, l = e & 63;
+                    img_f32[(tile * 16 + reg) * 64 + l] = src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + 32 * it + feat(reg, l >> 5)];
+                }
+                for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * 64 * 8; e += gridDim.x * blockDim.x) {
+                    const int s = e >> 9, l = (e >> 3) & 63, j = e & 7;
+                    const int k = 32 * it + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+                    const float w = src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + k];
+                    const unsigned short hi = f2bf_(w);
+                    const int idx = ((tile * 2 + s) * 64 + l) * 8 + j;
+                    img_bf[idx] = hi;
+                    img_bf[NFRAG_BF * 64 * 8 + idx] = f2bf_(w - bf2f_(hi));
+                }
+            }
+}
+
+// ---- Y^T tile += W[mat][nt][it] X^T, input in accumulator layout ----------------------------------------------
+template <int PREC>
+__device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, const f32x16& in, f32x16 acc, int lane) {
+    if constexpr (PREC == PREC_F32) {
+        const float* w = reinterpret_cast<const float*>(lds_img) + tile * 16 * 64 + lane;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[reg * 64], in[reg], acc, 0, 0, 0);
+    } else {
+        const unsigned short* whi = reinterpret_cast<const unsigned short*>(lds_img) + (tile * 2 * 64 + lane) * 8;
+        const unsigned short* wlo = whi + NFRAG_BF * 64 * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u16x8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = in[8 * s + j];
+                const unsigned short hi = f2bf_(v);
+                bh[j] = hi;
+                bl[j] = f2bf_(v - bf2f_(hi));
+            }
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(whi + s * 64 * 8);
+            const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh);
+            if constexpr (PREC == PREC_BF16X3) {
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(wlo + s * 64 * 8);
+                const bf16x8 blv = __builtin_bit_cast(bf16x8, bl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhv, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one reciprocal, one exponential, five fma
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float r = 1.0f - p * exp2f(-ax * ax * LOG2E_F);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f)); }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// LayerNorm over the 32 features of each row: 16 in this lane, 16 in lane ^ 32
+__device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gamma, const float* beta, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += y[i];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 32.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float t = y[i] - mean; q = fmaf(t, t, q); }
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + 1e-5f);
+    f32x16 o;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + 8 * g + 4 * h);
+        const float4 be = *reinterpret_cast<const float4*>(beta + 8 * g + 4 * h);
+        o[4 * g + 0] = fmaf((y[4 * g + 0] - mean) * rstd, ga.x, be.x);
+        o[4 * g + 1] = fmaf((y[4 * g + 1] - mean) * rstd, ga.y, be.y);
+        o[4 * g + 2] = fmaf((y[4 * g + 2] - mean) * rstd, ga.z, be.z);
+        o[4 * g + 3] = fmaf((y[4 * g + 3] - mean) * rstd, ga.w, be.w);
+    }
+    return o;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* img = smem;                                                  // 45056 B
+    float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(PREC == PREC_F32 ? (const void*)a.img_f32 : (const void*)a.img_bf);
+        uint4* dst = reinterpret_cast<uint4*>(img);
+        for (int i = threadIdx.x; i < IMG_F32_FLOATS / 4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < VEC_FLOATS; i += 256) vec[i] = a.vecs[i];
+    }
+    __syncthreads();
+    const float *bo = vec, *g2 = vec + 32, *be2 = vec + 64, *b2 = vec + 96, *g1 = vec + 128, *be1 = vec + 160, *b1 = vec + 192,
+                *bkv = vec + 320;
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int64_t n_rows = (int64_t)a.B * a.L;
+    const float sc = a.scale * LOG2E_F;
+    // time-token key / value of this lane's four heads (head = 2g + h)
+    float k0[4][4], v0[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 kk = *reinterpret_cast<const float4*>(a.key0 + (2 * g + h) * 4);
+        const float4 vv = *reinterpret_cast<const float4*>(a.key0 + D + (2 * g + h) * 4);
+        k0[g][0] = kk.x * sc; k0[g][1] = kk.y * sc; k0[g][2] = kk.z * sc; k0[g][3] = kk.w * sc;
+        v0[g][0] = vv.x; v0[g][1] = vv.y; v0[g][2] = vv.z; v0[g][3] = vv.w;
+    }
+
+    for (int64_t tile0 = (int64_t)wave_global * 32; tile0 < n_rows; tile0 += (int64_t)n_waves * 32) {
+        const int64_t row = min(tile0 + c, n_rows - 1);          // clamp: out-of-range lanes recompute the last row, never store
+        const bool live = tile0 + c < n_rows;
+        const int r = (int)(row % a.L);
+        // ---- attention output of layer 0 in accumulator layout: register 4g+i <-> feature 8g + 4h + i
+        f32x16 att;
+        if (r == 0) {
+            const float* ap = a.att0 + row * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(ap + 8 * g + 4 * h);
+                att[4 * g] = t.x; att[4 * g + 1] = t.y; att[4 * g + 2] = t.z; att[4 * g + 3] = t.w;
+            }
+        } else {
+            const float* qp = a.q + row * a.ldq;
+            const float* sp = a.state + row * (NH * 6);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hd = 2 * g + h;
+                const float4 q = *reinterpret_cast<const float4*>(qp + hd * 4);
+                const float2 ml = *reinterpret_cast<const float2*>(sp + hd * 6);
+                const float2 o01 = *reinterpret_cast<const float2*>(sp + hd * 6 + 2);
+                const float2 o23 = *reinterpret_cast<const float2*>(sp + hd * 6 + 4);
+                const float s = fmaf(q.x, k0[g][0], fmaf(q.y, k0[g][1], fmaf(q.z, k0[g][2], q.w * k0[g][3])));
+                const float mn = fmaxf(ml.x, s);
+                const float al = exp2f(ml.x - mn), p = exp2f(s - mn);
+                const float inv = __frcp_rn(fmaf(ml.y, al, p));
+                att[4 * g + 0] = fmaf(o01.x, al, p * v0[g][0]) * inv;
+                att[4 * g + 1] = fmaf(o01.y, al, p * v0[g][1]) * inv;
+                att[4 * g + 2] = fmaf(o23.x, al, p * v0[g][2]) * inv;
+                att[4 * g + 3] = fmaf(o23.y, al, p * v0[g][3]) * inv;
+            }
+        }
+        // ---- y1 = x0 + Wo att + bo
+        f32x16 y1 = mm<PREC>(img, tile_base(0), att, zero16(), lane);
+        {
+            const float* xp = a.x0 + row * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 x = *reinterpret_cast<const float4*>(xp + 8 * g + 4 * h);
+                const float4 b = *reinterpret_cast<const float4*>(bo + 8 * g + 4 * h);
+                y1[4 * g + 0] += x.x + b.x; y1[4 * g + 1] += x.y + b.y; y1[4 * g + 2] += x.z + b.z; y1[4 * g + 3] += x.w + b.w;
+            }
+        }
+        // ---- y2 = y1 + W2 gelu(W1 LN(y1) + b1) + b2, one 32-wide slice of the hidden layer at a time
+        const f32x16 hn = layer_norm32(y1, g2, be2, h);
+        f32x16 acc2 = zero16();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x16 f = mm<PREC>(img, tile_base(1) + nt, hn, zero16(), lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = *reinterpret_cast<const float4*>(b1 + 32 * nt + 8 * g + 4 * h);
+                f[4 * g + 0] = gelu_erf(f[4 * g + 0] + b.x); f[4 * g + 1] = gelu_erf(f[4 * g + 1] + b.y);
+                f[4 * g + 2] = gelu_erf(f[4 * g + 2] + b.z); f[4 * g + 3] = gelu_erf(f[4 * g + 3] + b.w);
+            }
+            acc2 = mm<PREC>(img, tile_base(2) + nt, f, acc2, lane);
+        }
+        f32x16 y2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(b2 + 8 * g + 4 * h);
+            y2[4 * g + 0] = y1[4 * g + 0] + acc2[4 * g + 0] + b.x; y2[4 * g + 1] = y1[4 * g + 1] + acc2[4 * g + 1] + b.y;
+            y2[4 * g + 2] = y1[4 * g + 2] + acc2[4 * g + 2] + b.z; y2[4 * g + 3] = y1[4 * g + 3] + acc2[4 * g + 3] + b.w;
+        }
+        // ---- layer 1: LayerNorm, K/V projection
+        const f32x16 gn = layer_norm32(y2, g1, be1, h);
+        if (live && r < a.n_keep) {        // rows the decoder can see: layer-1 residual input and its normalised copy
+            float* xo = a.x1 + row * D;
+            float* ho = a.h1 + row * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float4*>(xo + 8 * g + 4 * h) = make_float4(y2[4 * g], y2[4 * g + 1], y2[4 * g + 2], y2[4 * g + 3]);
+                *reinterpret_cast<float4*>(ho + 8 * g + 4 * h) = make_float4(gn[4 * g], gn[4 * g + 1], gn[4 * g + 2], gn[4 * g + 3]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x16 kv = mm<PREC>(img, tile_base(3) + nt, gn, zero16(), lane);
+            if (live) {
+                float* op = a.kv + row * a.ldkv + 32 * nt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = *reinterpret_cast<const float4*>(bkv + 32 * nt + 8 * g + 4 * h);
+                    *reinterpret_cast<float4*>(op + 8 * g + 4 * h) =
+                        make_float4(kv[4 * g] + b.x, kv[4 * g + 1] + b.y, kv[4 * g + 2] + b.z, kv[4 * g + 3] + b.w);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+size_t enc_rows_image_bytes() { return sizeof(float) * IMG_F32_FLOATS + sizeof(unsigned short) * IMG_BF_SHORTS; }
+
+hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, void* image, hipStream_t stream) {
+    ImageSrc s;
+    s.W[0] = Wo; s.W[1] = W1; s.W[2] = W2; s.W[3] = Wkv;
+    float* f = reinterpret_cast<float*>(image);
+    unsigned short* b = reinterpret_cast<unsigned short*>(f + IMG_F32_FLOATS);
+    hipLaunchKernelGGL(build_image_kernel, dim3(8), dim3(256), 0, stream, s, f, b);
+    return hipGetLastError();
+}
+
+hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
+    if (a0.B <= 0 || a0.L <= 0 || !a0.image) return hipErrorInvalidValue;
+    EncRowsArgs a = a0;
+    a.img_f32 = reinterpret_cast<const float*>(a.image);
+    a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
+    const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 32) * 4;
+    const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32;
+    int blocks = (int)((tiles + 3) / 4);
+    if (blocks > 512) blocks = 512;            // 2 workgroups per CU; waves stride over the remaining tiles
+    if (prec == PREC_F32) hipLaunchKernelGGL(enc_rows_kernel<PREC_F32>, dim3(blocks), dim3(256), smem, stream, a);
+    else if (prec == PREC_BF16) hipLaunchKernelGGL(enc_rows_kernel<PREC_BF16>, dim3(blocks), dim3(256), smem, stream, a);
+    else hipLaunchKernelGGL(enc_rows_kernel<PREC_BF16X3>, dim3(blocks), dim3(256), smem, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace adx

@@ -104,7 +104,7 @@ class Transformer(nn.Module):
                  n_prior_steps: int = 0, prior_dim: int = 0, n_layer: int = 4, n_head: int = 8, n_emb: int = 32,
                  p_drop_emb: float = 0.1, p_drop_attn: float = 0.1, causal_attn: bool = False, time_as_cond: bool = True,
                  obs_as_cond: bool = False, n_cond_layers: int = 2, map_cond: bool = True,
-                 precision: str = "fp32", elide: int = 2) -> None:
+                 precision: str = "fp32", elide: int = 3) -> None:
         super().__init__()
         if not time_as_cond or not causal_attn or cond_dim <= 0 or n_cond_layers <= 0:
             raise NotImplementedError("only the configuration the refiner instantiates is implemented: "
@@ -247,7 +247,7 @@ class TrajectoryRefiner(nn.Module):
             input_dim=cfg.trajectory_dim, output_dim=cfg.trajectory_dim, horizon=cfg.frame_stack,
             n_cond_steps=cfg.n_maps_token, cond_dim=cfg.maps_dim, n_prior_steps=cfg.frame_stack, prior_dim=cfg.trajectory_dim,
             causal_attn=True, map_cond=cfg.map_cond,
-            precision=getattr(cfg, "precision", "fp32"), elide=getattr(cfg, "elide", 2))
+            precision=getattr(cfg, "precision", "fp32"), elide=getattr(cfg, "elide", 3))
         self.diffusion = DiffusionWrapper(
             model, beta_schedule=cfg.beta_schedule, timesteps=cfg.diffusion_timesteps, objective=cfg.objective,
             sampling_timesteps=getattr(cfg, "sampling_timesteps", None),
@@ -315,7 +315,7 @@ class DiffusionAugmentation(nn.Module):
 def refiner_config(frame_stack: int = 10, diffusion_timesteps: int = 100, objective: str = "pred_noise",
                    beta_schedule: str = "cosine", ddim: float = 0.0, normalize: bool = True, residual: bool = False,
                    map_cond: bool = True, sampling_timesteps: Optional[int] = None, precision: str = "fp32",
-                   elide: int = 2) -> SimpleNamespace:
+                   elide: int = 3) -> SimpleNamespace:
     """The fields the CLI copies onto the model config (utils/args.py:154-183; str_base.py:1045-1053)."""
     return SimpleNamespace(trajectory_dim=4, frame_stack=frame_stack, n_maps_token=788, maps_dim=256, map_cond=map_cond,
                            beta_schedule=beta_schedule, diffusion_timesteps=diffusion_timesteps, objective=objective,

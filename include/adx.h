@@ -102,7 +102,8 @@ typedef struct adx_model_config {
     int precision;      /* ADX_PREC_* */
     int elide;          /* 0: every op of the reference; 1: skip work whose result the masks make unobservable;
                            2: also reuse, within a chunk, the encoder layer-0 attention of all step-invariant rows
-                              (both exact in real arithmetic; 2 re-associates one softmax sum) */
+                              (both exact in real arithmetic; 2 re-associates one softmax sum);
+                           3: as 2, with the per-row encoder pipeline fused into one kernel (d_model 32, 8 heads, 2 layers) */
     int d_model;        /* n_emb (A) / feat_dim = n_embd (DiT) */
     int n_head;
     int n_enc_layers;   /* A: n_cond_layers */

@@ -132,7 +132,7 @@ def test_op_normalize_sched_step(dev, golden):
 
 
 # ------------------------------------------------------------------ variant A
-def make_a(fs, flat=False, precision="fp32", elide=2, dev="cuda:0"):
+def make_a(fs, flat=False, precision="fp32", elide=3, dev="cuda:0"):
     from autodiffusion_amd import refiner, synth
     if flat:
         m = refiner.Transformer(input_dim=4 * fs, output_dim=4 * fs, horizon=1, n_cond_steps=788, cond_dim=256, n_prior_steps=1,
@@ -215,7 +215,7 @@ def test_ddim_loop_trace(dev, golden, obj, eta):
 @pytest.mark.parametrize("tag,fs,residual,obj,sched", [("fs10", 10, False, "pred_noise", "cosine"),
                                                        ("fs10_res", 10, True, "pred_x0", "sigmoid"),
                                                        ("fs80", 80, True, "pred_x0", "sigmoid")])
-@pytest.mark.parametrize("graph,elide", [(True, 2), (False, 2), (True, 1), (True, 0)])
+@pytest.mark.parametrize("graph,elide", [(True, 3), (False, 3), (True, 2), (True, 1), (True, 0)])
 def test_generate_chunk_loop(dev, golden, tag, fs, residual, obj, sched, graph, elide):
     from autodiffusion_amd import _lib, refiner, synth
     g = golden("g8_chunk_loop")
