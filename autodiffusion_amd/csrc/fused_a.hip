@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
         // ---- y2 = y1 + W2 gelu(W1 LN(y1) + b1) + b2, one 32-wide slice of the hidden layer at a time
         const f32x16 hn = layer_norm32(y1, g2, be2, h);
         f32x16 acc2 = zero16();
-#pragma unroll
+#pragma unroll 1
         for (int nt = 0; nt < 4; ++nt) {
             f32x16 f = mm<PREC>(img, tile_base(1) + nt, hn, zero16(), lane);
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
                 *reinterpret_cast<float4*>(ho + 8 * g + 4 * h) = make_float4(gn[4 * g], gn[4 * g + 1], gn[4 * g + 2], gn[4 * g + 3]);
             }
         }
-#pragma unroll
+#pragma unroll 1
         for (int nt = 0; nt < 2; ++nt) {
             const f32x16 kv = mm<PREC>(img, tile_base(3) + nt, gn, zero16(), lane);
             if (live) {
