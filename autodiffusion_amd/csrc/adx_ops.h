@@ -94,14 +94,16 @@ struct EncRowsArgs {
     const float* key0 = nullptr;                     // [64]
     const void* image = nullptr;                     // weight fragment image from enc_rows_build_image
     const float* img_f32 = nullptr; const unsigned short* img_bf = nullptr;   // filled by the launcher
-    const float* vecs = nullptr;                     // [384] bo, gamma2, beta2, b2, gamma1', beta1', b1(128), bkv(64)
+    const float* vecs = nullptr;                     // [416] bo, gamma2, beta2, b2, gamma1', beta1', b1(128), bkv(64), bq(32)
     float* kv = nullptr; int64_t ldkv = 0;           // K at kv[row*ldkv + 0..31], V at +32..63
-    float* x1 = nullptr; float* h1 = nullptr;        // [B*L][32]
+    float* x1 = nullptr;                             // [B*L][32] layer-1 residual input, rows r < n_keep only
+    float* q1 = nullptr; int64_t ldq1 = 0;           // layer-1 queries, rows r < n_keep only
     int B = 0, L = 0, n_keep = 0;
     float scale = 1.f;
 };
 size_t enc_rows_image_bytes();
-hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, void* image, hipStream_t stream);
+hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, const float* Wq, void* image,
+                                hipStream_t stream);
 hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);
 
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
@@ -130,6 +132,30 @@ hipError_t affine_channels(const float* x, const float* mean, const float* std, 
 struct StepCoef { float t, a0, a1, clip, eps_mode, b0, b1, c0, c1, c2, c3, z_index; };
 hipError_t sched_step(const float* x, const float* model_out, const float* z, float* x_next, float* x0_out,
                       int64_t n, const StepCoef* coef_dev, hipStream_t stream);
+
+// Fused tail of a variant-A denoiser call + scheduler update; see tail_a.hip.  All offsets index the float buffer `w`
+// (matrices packed [K/4][N][4] by tail_pack_matrix, vectors copied as they are).
+struct TailMat { int w_off = 0, b_off = 0, N = 0, K = 0; };
+struct TailLayer {
+    int ln1_g = 0, ln1_b = 0, ln2_g = 0, ln2_b = 0, ln3_g = 0, ln3_b = 0;
+    TailMat wqkv, wo, wq, wkv, wo2, w1, w2;
+};
+struct TailArgs {
+    const float* w = nullptr;
+    const float* att1 = nullptr;      // [B*L][32] last encoder layer attention output, rows 0..T of each item
+    const float* x1 = nullptr;        // [B*L][32] its residual input, rows 0..T
+    const float* x = nullptr;         // [B][T][C] x_t
+    const float* z = nullptr;         // [B][T][C] noise of this step or nullptr
+    const StepCoef* coef = nullptr;   // device
+    float* x_next = nullptr;          // [B][T][C]
+    float* model_out = nullptr;       // [B][T][C] or nullptr
+    int B = 0, L = 0, T = 0, C = 0, n_dec = 0;
+    int e_ln2_g = 0, e_ln2_b = 0, lnf_g = 0, lnf_b = 0, pos_off = 0;
+    TailMat e_wo, e_w1, e_w2, d_in, d_head;
+    TailLayer dec[4];
+};
+hipError_t tail_pack_matrix(const float* W, int N, int K, float* out, hipStream_t stream);
+hipError_t tail_a(const TailArgs& a, hipStream_t stream);
 
 // f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);

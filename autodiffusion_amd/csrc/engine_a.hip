@@ -25,6 +25,13 @@ using namespace adx;
 
 namespace {
 
+// What a sampling step hands to run_net so that the fused tail can also apply the scheduler update.
+struct StepIO {
+    int step = -1;                  // row of the schedule tables; < 0: plain denoiser call (no caches)
+    const float* z = nullptr;       // noise of this step or nullptr
+    float* x_next = nullptr;        // receives x_{t-1} when the tail kernel runs
+};
+
 struct EngineA final : adx_engine {
     int d, H, L, T, NP, Cin, Cout, Cp, nmaps, n_enc, n_dec, Lm;
     // workspace pointers
@@ -41,11 +48,16 @@ struct EngineA final : adx_engine {
     bool fused = false;
     void* rows_image = nullptr;
     float* rows_vecs = nullptr;
+    // fused tail (rest of the last encoder layer + decoder + head + scheduler update in one launch)
+    bool tail_ok = false;
+    float* tail_w = nullptr;
+    TailArgs tail_tpl;
 
     ~EngineA() override {
         if (tqkv0) (void)hipFree(tqkv0);
         if (rows_image) (void)hipFree(rows_image);
         if (rows_vecs) (void)hipFree(rows_vecs);
+        if (tail_w) (void)hipFree(tail_w);
     }
 
     explicit EngineA(const adx_model_config& c) {
@@ -58,6 +70,7 @@ struct EngineA final : adx_engine {
         fast4 = (H == 8 && d == 32);
         if (cfg.elide >= 2 && !fast4) cfg.elide = 1;
         fused = cfg.elide >= 3 && n_enc == 2;
+        tail_ok = fused && T + 1 <= 12 && Cin == Cout && Cin <= 64 && (Cin % 4) == 0 && n_dec <= 4;
     }
 
     std::vector<ParamSpec> expected_params() const override {
@@ -133,18 +146,74 @@ struct EngineA final : adx_engine {
         }
         if (fused) {
             if (!rows_image) ADX_HIP(hipMalloc(&rows_image, enc_rows_image_bytes()));
-            if (!rows_vecs) ADX_HIP(hipMalloc(&rows_vecs, sizeof(float) * 384));
+            if (!rows_vecs) ADX_HIP(hipMalloc(&rows_vecs, sizeof(float) * 416));
             const std::string p0 = "encoder.layers.0", p1 = "encoder.layers.1";
             ADX_HIP(enc_rows_build_image(P(p0 + ".self_attn.out_proj.weight"), P(p0 + ".linear1.weight"), P(p0 + ".linear2.weight"),
-                                         P(p1 + ".self_attn.in_proj_weight") + (int64_t)d * d, rows_image, s));
+                                         P(p1 + ".self_attn.in_proj_weight") + (int64_t)d * d, P(p1 + ".self_attn.in_proj_weight"),
+                                         rows_image, s));
             struct { const float* src; int off, n; } parts[] = {
                 {P(p0 + ".self_attn.out_proj.bias"), 0, 32}, {P(p0 + ".norm2.weight"), 32, 32}, {P(p0 + ".norm2.bias"), 64, 32},
                 {P(p0 + ".linear2.bias"), 96, 32}, {P(p1 + ".norm1.weight"), 128, 32}, {P(p1 + ".norm1.bias"), 160, 32},
-                {P(p0 + ".linear1.bias"), 192, 128}, {P(p1 + ".self_attn.in_proj_bias") + d, 320, 64}};
+                {P(p0 + ".linear1.bias"), 192, 128}, {P(p1 + ".self_attn.in_proj_bias") + d, 320, 64},
+                {P(p1 + ".self_attn.in_proj_bias"), 384, 32}};
             for (const auto& q : parts)
                 ADX_HIP(hipMemcpyAsync(rows_vecs + q.off, q.src, sizeof(float) * q.n, hipMemcpyDeviceToDevice, s));
             ADX_HIP(hipStreamSynchronize(s));
         }
+        if (tail_ok) ADX_TRY(build_tail_pack(s));
+        return ADX_OK;
+    }
+
+    // Pack every matrix / vector the fused tail reads into one float buffer and record the offsets.
+    int build_tail_pack(hipStream_t s) {
+        std::vector<std::pair<const float*, int>> vec_copies;      // (src, n) in buffer order
+        struct MatJob { const float* W; int N, K, off; };
+        std::vector<MatJob> mats;
+        int off = 0;
+        std::vector<int> vec_dst;
+        auto vec = [&](const float* src, int n) { int o = off; vec_copies.push_back({src, n}); vec_dst.push_back(o); off += (n + 3) / 4 * 4; return o; };
+        auto mat = [&](const std::string& wname, int row0, int N, int K, const std::string& bname) {
+            TailMat m;
+            m.N = N; m.K = K;
+            m.b_off = vec(P(bname) + row0, N);
+            m.w_off = off;
+            mats.push_back({P(wname) + (int64_t)row0 * K, N, K, off});
+            off += N * K;
+            return m;
+        };
+        TailArgs t;
+        const std::string e1 = "encoder.layers." + std::to_string(n_enc - 1);
+        t.e_wo = mat(e1 + ".self_attn.out_proj.weight", 0, d, d, e1 + ".self_attn.out_proj.bias");
+        t.e_ln2_g = vec(P(e1 + ".norm2.weight"), d); t.e_ln2_b = vec(P(e1 + ".norm2.bias"), d);
+        t.e_w1 = mat(e1 + ".linear1.weight", 0, 4 * d, d, e1 + ".linear1.bias");
+        t.e_w2 = mat(e1 + ".linear2.weight", 0, d, 4 * d, e1 + ".linear2.bias");
+        t.d_in = mat("input_emb.weight", 0, d, Cin, "input_emb.bias");
+        t.pos_off = vec(P("pos_emb"), T * d);
+        for (int i = 0; i < n_dec; ++i) {
+            const std::string p = "decoder.layers." + std::to_string(i);
+            TailLayer& l = t.dec[i];
+            l.ln1_g = vec(P(p + ".norm1.weight"), d); l.ln1_b = vec(P(p + ".norm1.bias"), d);
+            l.ln2_g = vec(P(p + ".norm2.weight"), d); l.ln2_b = vec(P(p + ".norm2.bias"), d);
+            l.ln3_g = vec(P(p + ".norm3.weight"), d); l.ln3_b = vec(P(p + ".norm3.bias"), d);
+            l.wqkv = mat(p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias");
+            l.wo = mat(p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias");
+            l.wq = mat(p + ".multihead_attn.in_proj_weight", 0, d, d, p + ".multihead_attn.in_proj_bias");
+            l.wkv = mat(p + ".multihead_attn.in_proj_weight", d, 2 * d, d, p + ".multihead_attn.in_proj_bias");
+            l.wo2 = mat(p + ".multihead_attn.out_proj.weight", 0, d, d, p + ".multihead_attn.out_proj.bias");
+            l.w1 = mat(p + ".linear1.weight", 0, 4 * d, d, p + ".linear1.bias");
+            l.w2 = mat(p + ".linear2.weight", 0, d, 4 * d, p + ".linear2.bias");
+        }
+        t.lnf_g = vec(P("ln_f.weight"), d); t.lnf_b = vec(P("ln_f.bias"), d);
+        t.d_head = mat("head.weight", 0, Cout, d, "head.bias");
+        if (tail_w) (void)hipFree(tail_w);
+        tail_w = nullptr;
+        ADX_HIP(hipMalloc(&tail_w, sizeof(float) * (size_t)off));
+        ADX_HIP(hipMemsetAsync(tail_w, 0, sizeof(float) * (size_t)off, s));
+        for (const MatJob& j : mats) ADX_HIP(tail_pack_matrix(j.W, j.N, j.K, tail_w + j.off, s));
+        for (size_t i = 0; i < vec_copies.size(); ++i)
+            ADX_HIP(hipMemcpyAsync(tail_w + vec_dst[i], vec_copies[i].first, sizeof(float) * vec_copies[i].second, hipMemcpyDeviceToDevice, s));
+        ADX_HIP(hipStreamSynchronize(s));
+        tail_tpl = t;
         return ADX_OK;
     }
 
@@ -200,32 +269,63 @@ struct EngineA final : adx_engine {
     }
 
     // ---------------------------------------------------------------------------------- the network
+    AttentionArgs enc_attn_args(int B, int rq) const {
+        const int dh = d / H;
+        AttentionArgs at;
+        at.Q = QKV; at.ldq = 3 * d; at.q_batch_stride = (int64_t)L * 3 * d;
+        at.K = QKV + d; at.ldk = 3 * d; at.k_batch_stride = (int64_t)L * 3 * d;
+        at.V = QKV + 2 * d; at.ldv = 3 * d; at.v_batch_stride = (int64_t)L * 3 * d;
+        at.O = ATT; at.ldo = d; at.o_batch_stride = (int64_t)L * d;
+        at.B = B; at.H = H; at.Sq = rq; at.Skv = L; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
+        return at;
+    }
+
+    // attention of the time token (row 0) under layer 0, against the cached keys plus its own per-step key
+    int time_token_attention(int B, int step, hipStream_t s) {
+        const int dh = d / H;
+        const float* tq = tqkv0 + (int64_t)step * 3 * d;
+        AttentionArgs a0;
+        a0.Q = tq; a0.ldq = 3 * d; a0.q_batch_stride = 0;
+        a0.K = QKV0 + d; a0.V = QKV0 + 2 * d; a0.ldk = a0.ldv = 3 * d; a0.k_batch_stride = a0.v_batch_stride = (int64_t)L * 3 * d;
+        a0.O = ATT; a0.ldo = d; a0.o_batch_stride = (int64_t)L * d;
+        a0.B = B; a0.H = H; a0.Sq = 1; a0.Skv = L; a0.dh = dh; a0.dv = dh; a0.scale = 1.0f / sqrtf((float)dh); a0.key0 = tq + d;
+        ADX_HIP(attention_few_queries(a0, s));
+        return ADX_OK;
+    }
+
     // X0 must hold the conditioning rows; x is (B,T,Cin); out is (B,T,Cout).
-    // step >= 0 selects the cached layer-0 attention of elide level 2 (row `step` of tqkv0).
-    int run_net(int B, const float* x, float* out, hipStream_t s, int step = -1) {
+    // Returns ADX_OK; *stepped is set when the scheduler update was applied too (fused tail).
+    int run_net(int B, const float* x, float* out, hipStream_t s, const StepIO& io = StepIO(), bool* stepped = nullptr) {
         const int dh = d / H;
         const float scale = 1.0f / sqrtf((float)dh);
+        const int step = io.step;
+        if (stepped) *stepped = false;
         const float* cur = X0;
         int first_layer = 0;
-        bool kv_done = false;
+        bool last_attn_done = false;      // ATT already holds the last encoder layer's attention for rows 0..T
         if (step >= 0 && fused) {
-            // layer 0 + layer 1's LayerNorm and K/V projection in two launches
+            // layer 0 and layer 1 up to its attention: three launches
+            ADX_TRY(time_token_attention(B, step, s));
             const float* tq = tqkv0 + (int64_t)step * 3 * d;
-            AttentionArgs a0;
-            a0.Q = tq; a0.ldq = 3 * d; a0.q_batch_stride = 0;
-            a0.K = QKV0 + d; a0.V = QKV0 + 2 * d; a0.ldk = a0.ldv = 3 * d; a0.k_batch_stride = a0.v_batch_stride = (int64_t)L * 3 * d;
-            a0.O = ATT; a0.ldo = d; a0.o_batch_stride = (int64_t)L * d;
-            a0.B = B; a0.H = H; a0.Sq = 1; a0.Skv = L; a0.dh = dh; a0.dv = dh; a0.scale = scale; a0.key0 = tq + d;
-            ADX_HIP(attention_few_queries(a0, s));
             EncRowsArgs r;
             r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.att0 = ATT; r.key0 = tq + d;
             r.image = rows_image; r.vecs = rows_vecs;
-            r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.h1 = H1;
+            r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
             r.B = B; r.L = L; r.n_keep = T + 1; r.scale = scale;
             ADX_HIP(enc_rows(r, cfg.precision, s));
+            ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
+            if (tail_ok && io.x_next && stepped) {
+                TailArgs t = tail_tpl;
+                t.w = tail_w; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = io.z; t.coef = steps_dev + step;
+                t.x_next = io.x_next; t.model_out = out;
+                t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
+                ADX_HIP(tail_a(t, s));
+                *stepped = true;
+                return ADX_OK;
+            }
             cur = XA;
             first_layer = 1;
-            kv_done = true;
+            last_attn_done = true;
         }
         // ---- encoder (pre-norm, GELU)
         for (int i = first_layer; i < n_enc; ++i) {
@@ -234,42 +334,30 @@ struct EngineA final : adx_engine {
             const bool last = cfg.elide && i == n_enc - 1;
             const int rq = last ? T + 1 : L;                      // query rows per batch item
             const RowMap qmap = last ? RowMap{rq, L, 0} : RowMap{};
-            if (i == 0 && step >= 0 && !last) {
+            if (i == 0 && step >= 0 && cfg.elide >= 2 && !last) {
                 // layer-0 attention from the chunk cache: only the time token (row 0) changed since the cache was built
+                ADX_TRY(time_token_attention(B, step, s));
                 const float* tq = tqkv0 + (int64_t)step * 3 * d;
-                AttentionArgs a0;
-                a0.Q = tq; a0.ldq = 3 * d; a0.q_batch_stride = 0;
-                a0.K = QKV0 + d; a0.V = QKV0 + 2 * d; a0.ldk = a0.ldv = 3 * d; a0.k_batch_stride = a0.v_batch_stride = (int64_t)L * 3 * d;
-                a0.O = ATT; a0.ldo = d; a0.o_batch_stride = (int64_t)L * d;
-                a0.B = B; a0.H = H; a0.Sq = 1; a0.Skv = L; a0.dh = dh; a0.dv = dh; a0.scale = scale; a0.key0 = tq + d;
-                ADX_HIP(attention_few_queries(a0, s));
                 AttentionArgs a1;
                 a1.Q = QKV0 + 3 * d; a1.ldq = 3 * d; a1.q_batch_stride = (int64_t)L * 3 * d;
                 a1.O = ATT + d; a1.ldo = d; a1.o_batch_stride = (int64_t)L * d;
                 a1.B = B; a1.H = H; a1.Sq = L - 1; a1.dh = dh; a1.dv = dh; a1.scale = scale; a1.key0 = tq + d;
                 a1.state = ST + H * 6; a1.state_ld = H * 6; a1.state_batch_stride = (int64_t)L * H * 6;
                 ADX_HIP(attention_merge_key(a1, s));
-            } else {
-            if (!(last && kv_done)) ADX_TRY(ln_rows(cur, H1, p + ".norm1", B * L, RowMap{}, s));
-            if (!last) {
-                ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * L), s));
-            } else {
-                if (!kv_done) {
+            } else if (!(last && last_attn_done)) {
+                ADX_TRY(ln_rows(cur, H1, p + ".norm1", B * L, RowMap{}, s));
+                if (!last) {
+                    ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * L), s));
+                } else {
                     LinearArgs kv = lin(H1, d, p + ".self_attn.in_proj_weight", d, 2 * d, d, p + ".self_attn.in_proj_bias", QKV + d, 3 * d, B * L);
                     ADX_HIP(linear(kv, s));
+                    LinearArgs q = lin(H1, d, p + ".self_attn.in_proj_weight", 0, d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * rq);
+                    q.xmap = qmap; q.ymap = qmap;
+                    ADX_HIP(linear(q, s));
                 }
-                LinearArgs q = lin(H1, d, p + ".self_attn.in_proj_weight", 0, d, d, p + ".self_attn.in_proj_bias", QKV, 3 * d, B * rq);
-                q.xmap = qmap; q.ymap = qmap;
-                ADX_HIP(linear(q, s));
-            }
-            AttentionArgs at;
-            at.Q = QKV; at.ldq = 3 * d; at.q_batch_stride = (int64_t)L * 3 * d;
-            at.K = QKV + d; at.ldk = 3 * d; at.k_batch_stride = (int64_t)L * 3 * d;
-            at.V = QKV + 2 * d; at.ldv = 3 * d; at.v_batch_stride = (int64_t)L * 3 * d;
-            at.O = ATT; at.ldo = d; at.o_batch_stride = (int64_t)L * d;
-            at.B = B; at.H = H; at.Sq = rq; at.Skv = L; at.dh = dh; at.dv = dh; at.scale = scale; at.mask_off = -1;
-            if (last && fast4) ADX_HIP(attention_few_queries(at, s));
-            else ADX_HIP(attention(at, s));
+                const AttentionArgs at = enc_attn_args(B, rq);
+                if (last && fast4) ADX_HIP(attention_few_queries(at, s));
+                else ADX_HIP(attention(at, s));
             }
             LinearArgs o = lin(ATT, d, p + ".self_attn.out_proj.weight", 0, d, d, p + ".self_attn.out_proj.bias", nxt, d, B * rq);
             o.xmap = qmap; o.ymap = qmap; o.res = cur; o.ldr = d;
@@ -284,7 +372,7 @@ struct EngineA final : adx_engine {
             cur = nxt;
         }
         const float* memory = cur;   // (B, L, d); with elide only rows 0..T of each item are defined
-        // ---- decoder (pre-norm, GELU): causal self-attention, masked cross-attention, FFN
+        // ---- decoder (pre-norm, GELU): causal self-attention, masked cross-attention, FFN.  Always fp32.
         {
             LinearArgs e = lin(x, Cin, "input_emb.weight", 0, d, Cin, "input_emb.bias", Y, d, B * T, ACT_NONE, PREC_F32);
             e.pos = P("pos_emb"); e.ldp = d; e.pos_period = T; e.pos_off = 0;
@@ -372,16 +460,19 @@ struct EngineA final : adx_engine {
         else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, s));
         for (size_t k = 0; k < steps.size(); ++k) {
             ADX_TRY(set_time(B, temb_table + k * d, 0, s));
-            ADX_TRY(run_net(B, xc, MOUT, s, cached ? (int)k : -1));
-            if (trace_x) ADX_HIP(copy2d(xc, n, 0, trace_x + k * n, n, 1, (int)n, s));
-            if (trace_out) ADX_HIP(copy2d(MOUT, n, 0, trace_out + k * n, n, 1, (int)n, s));
             const int zi = (int)steps[k].z_index;
             const float* z = nullptr;
             if (zi >= 0 && steps[k].c3 != 0.f) {
                 if (1 + zi >= n_noise) { set_error("sample_a: schedule draws more noise tensors than were supplied"); return ADX_EINVAL; }
                 z = noise + (int64_t)(1 + zi) * n;
             }
-            ADX_HIP(sched_step(xc, MOUT, z, xn, nullptr, n, steps_dev + k, s));
+            StepIO io;
+            io.step = cached ? (int)k : -1; io.z = z; io.x_next = xn;
+            bool stepped = false;
+            ADX_TRY(run_net(B, xc, MOUT, s, io, &stepped));
+            if (trace_x) ADX_HIP(copy2d(xc, n, 0, trace_x + k * n, n, 1, (int)n, s));
+            if (trace_out) ADX_HIP(copy2d(MOUT, n, 0, trace_out + k * n, n, 1, (int)n, s));
+            if (!stepped) ADX_HIP(sched_step(xc, MOUT, z, xn, nullptr, n, steps_dev + k, s));
             float* tmp = xc; xc = xn; xn = tmp;
         }
         // un-normalise (+ residual) into CHO, then place the chunk

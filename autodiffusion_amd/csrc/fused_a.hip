@@ -17,6 +17,8 @@
 // The weight fragments are pre-arranged in exactly that k order by build_image_kernel and staged in LDS once per
 // workgroup.  LayerNorm reduces 16 registers in-lane plus one exchange with lane l ^ 32.
 //
+// Rows r < n_keep of every batch item (the ones the decoder can see) also get the layer-1 query projection.
+//
 // HBM traffic per row and step (f32): read x0 128 B, q 128 B, softmax state 192 B; write k/v 256 B  -> 704 B.
 #include "adx_ops.h"
 
@@ -30,21 +32,21 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 namespace {
 
-constexpr int D = 32, FF = 128, NH = 8;
+constexpr int D = 32, NH = 8;
 constexpr float LOG2E_F = 1.4426950408889634f;
 
 // ---- fragment image -------------------------------------------------------------------------------------------
-// matrices in image order: Wo (32x32), W1 (128x32), W2 (32x128), Wkv (64x32)
+// matrices in image order: Wo (32x32), W1 (128x32), W2 (32x128), Wkv (64x32), Wq (32x32, layer 1)
 // F32   : fragment (mat, nt, it, reg)  = 64 floats: lane l -> W[32 nt + (l & 31)][32 it + f(reg, l >> 5)]
 // BF16X3: fragment (mat, nt, it, s)    = 64 lanes x 8 bf16 (hi image, then lo image)
-constexpr int NFRAG_F32 = 16 * (1 + 4 + 4 + 2);          // 176 fragments of 256 B
-constexpr int NFRAG_BF = 2 * (1 + 4 + 4 + 2);            // 22 fragments of 1 KiB per half
-constexpr int IMG_F32_FLOATS = NFRAG_F32 * 64;           // 11264 floats = 45056 B
-constexpr int IMG_BF_SHORTS = 2 * NFRAG_BF * 64 * 8;     // hi + lo: 22528 shorts = 45056 B
-constexpr int VEC_FLOATS = 32 * 6 + 128 + 64;            // bo g2 be2 b2 g1 be1 (6 x 32) + b1 (128) + bkv (64) = 384
+constexpr int NFRAG_F32 = 16 * (1 + 4 + 4 + 2 + 1);      // 192 fragments of 256 B
+constexpr int NFRAG_BF = 2 * (1 + 4 + 4 + 2 + 1);        // 24 fragments of 1 KiB per half
+constexpr int IMG_F32_FLOATS = NFRAG_F32 * 64;           // 12288 floats = 49152 B
+constexpr int IMG_BF_SHORTS = 2 * NFRAG_BF * 64 * 8;     // hi + lo: 24576 shorts = 49152 B
+constexpr int VEC_FLOATS = 32 * 6 + 128 + 64 + 32;       // bo g2 be2 b2 g1 be1 (6 x 32) + b1 (128) + bkv (64) + bq (32) = 416
 
 // base fragment index of each matrix (in units of "nt, it" tiles)
-__host__ __device__ constexpr int tile_base(int mat) { return mat == 0 ? 0 : (mat == 1 ? 1 : (mat == 2 ? 5 : 9)); }
+__host__ __device__ constexpr int tile_base(int mat) { return mat == 0 ? 0 : (mat == 1 ? 1 : (mat == 2 ? 5 : (mat == 3 ? 9 : 11))); }
 // number of input tiles (K / 32) of each matrix
 __host__ __device__ constexpr int in_tiles(int mat) { return mat == 2 ? 4 : 1; }
 
@@ -58,14 +60,14 @@ __device__ __forceinline__ unsigned short f2bf_(float f) {
 __device__ __forceinline__ float bf2f_(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
 struct ImageSrc {
-    const float* W[4];   // Wo [32][32], W1 [128][32], W2 [32][128], Wkv [64][32]
+    const float* W[5];   // Wo [32][32], W1 [128][32], W2 [32][128], Wkv [64][32], Wq [32][32]
 };
 
 __global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short* img_bf) {
-    const int nt_count[4] = {1, 4, 1, 2};
-    const int Kdim[4] = {32, 32, 128, 32};
+    const int nt_count[5] = {1, 4, 1, 2, 1};
+    const int Kdim[5] = {32, 32, 128, 32, 32};
     int tile = 0;
-    for (int mat = 0; mat < 4; ++mat)
+    for (int mat = 0; mat < 5; ++mat)
         for (int nt = 0; nt < nt_count[mat]; ++nt)
             for (int it = 0; it < in_tiles(mat); ++it, ++tile) {
                 for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 16 * 64; e += gridDim.x * blockDim.x) {
@@ -163,7 +165,7 @@ __device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gam
 template <int PREC>
 __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* img = smem;                                                  // 45056 B
+    unsigned char* img = smem;                                                  // 49152 B
     float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats
     {
         const uint4* src = reinterpret_cast<const uint4*>(PREC == PREC_F32 ? (const void*)a.img_f32 : (const void*)a.img_bf);
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
     }
     __syncthreads();
     const float *bo = vec, *g2 = vec + 32, *be2 = vec + 64, *b2 = vec + 96, *g1 = vec + 128, *be1 = vec + 160, *b1 = vec + 192,
-                *bkv = vec + 320;
+                *bkv = vec + 320, *bq = vec + 384;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const int64_t n_rows = (int64_t)a.B * a.L;
@@ -255,13 +257,19 @@ __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
         }
         // ---- layer 1: LayerNorm, K/V projection
         const f32x16 gn = layer_norm32(y2, g1, be1, h);
-        if (live && r < a.n_keep) {        // rows the decoder can see: layer-1 residual input and its normalised copy
-            float* xo = a.x1 + row * D;
-            float* ho = a.h1 + row * D;
+        const bool keep = live && r < a.n_keep;     // rows the decoder can see: they also need the layer-1 residual and query
+        if (__any(keep)) {                          // wave-uniform: ~1 tile in 25 holds the head of a batch item
+            const f32x16 q1 = mm<PREC>(img, tile_base(4), gn, zero16(), lane);
+            if (keep) {
+                float* xo = a.x1 + row * D;
+                float* qo = a.q1 + row * a.ldq1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<float4*>(xo + 8 * g + 4 * h) = make_float4(y2[4 * g], y2[4 * g + 1], y2[4 * g + 2], y2[4 * g + 3]);
-                *reinterpret_cast<float4*>(ho + 8 * g + 4 * h) = make_float4(gn[4 * g], gn[4 * g + 1], gn[4 * g + 2], gn[4 * g + 3]);
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = *reinterpret_cast<const float4*>(bq + 8 * g + 4 * h);
+                    *reinterpret_cast<float4*>(xo + 8 * g + 4 * h) = make_float4(y2[4 * g], y2[4 * g + 1], y2[4 * g + 2], y2[4 * g + 3]);
+                    *reinterpret_cast<float4*>(qo + 8 * g + 4 * h) =
+                        make_float4(q1[4 * g] + b.x, q1[4 * g + 1] + b.y, q1[4 * g + 2] + b.z, q1[4 * g + 3] + b.w);
+                }
             }
         }
 #pragma unroll 1
@@ -284,9 +292,10 @@ __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
 
 size_t enc_rows_image_bytes() { return sizeof(float) * IMG_F32_FLOATS + sizeof(unsigned short) * IMG_BF_SHORTS; }
 
-hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, void* image, hipStream_t stream) {
+hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, const float* Wq, void* image,
+                                hipStream_t stream) {
     ImageSrc s;
-    s.W[0] = Wo; s.W[1] = W1; s.W[2] = W2; s.W[3] = Wkv;
+    s.W[0] = Wo; s.W[1] = W1; s.W[2] = W2; s.W[3] = Wkv; s.W[4] = Wq;
     float* f = reinterpret_cast<float*>(image);
     unsigned short* b = reinterpret_cast<unsigned short*>(f + IMG_F32_FLOATS);
     hipLaunchKernelGGL(build_image_kernel, dim3(8), dim3(256), 0, stream, s, f, b);
@@ -298,7 +307,7 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     EncRowsArgs a = a0;
     a.img_f32 = reinterpret_cast<const float*>(a.image);
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
-    const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 32) * 4;
+    const size_t smem = IMG_F32_FLOATS * 4 + VEC_FLOATS * 4;
     const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32;
     int blocks = (int)((tiles + 3) / 4);
     if (blocks > 512) blocks = 512;            // 2 workgroups per CU; waves stride over the remaining tiles
