@@ -420,6 +420,37 @@ struct EngineA final : adx_engine {
         return ADX_OK;
     }
 
+    // Launch ONE stage of a sampling step on the current workspace contents, `iters` times (for timing a kernel in
+    // isolation with events on `s`).  Stages: 0 time-token attention, 1 fused encoder rows, 2 last-layer attention,
+    // 3 fused tail, 4 per-chunk cache build.  Needs a previous generate/sample call with the same B.
+    int debug_stage(int B, int stage, int iters, hipStream_t s) {
+        if (!finalized || steps.empty() || B > max_batch || !fused) { set_error("debug_stage: engine not ready (needs elide 3, a schedule and a prior call)"); return ADX_ESTATE; }
+        const int dh = d / H;
+        const float scale = 1.0f / sqrtf((float)dh);
+        const float* tq = tqkv0;
+        for (int it = 0; it < iters; ++it) {
+            if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
+            else if (stage == 1) {
+                EncRowsArgs r;
+                r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.att0 = ATT; r.key0 = tq + d;
+                r.image = rows_image; r.vecs = rows_vecs;
+                r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
+                r.B = B; r.L = L; r.n_keep = T + 1; r.scale = scale;
+                ADX_HIP(enc_rows(r, cfg.precision, s));
+            } else if (stage == 2) ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
+            else if (stage == 3) {
+                if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
+                TailArgs t = tail_tpl;
+                t.w = tail_w; t.att1 = ATT; t.x1 = XA; t.x = XS0; t.z = nullptr; t.coef = steps_dev;
+                t.x_next = XS1; t.model_out = MOUT;
+                t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
+                ADX_HIP(tail_a(t, s));
+            } else if (stage == 4) ADX_TRY(build_chunk_cache(B, s));
+            else { set_error("debug_stage: unknown stage"); return ADX_EINVAL; }
+        }
+        return ADX_OK;
+    }
+
     int check_ready(int B, const char* who) {
         if (!finalized) { set_error(std::string(who) + ": engine is not finalized"); return ADX_ESTATE; }
         if (B <= 0) { set_error(std::string(who) + ": batch must be positive"); return ADX_EINVAL; }
@@ -567,6 +598,12 @@ ADX_API int adx_denoise_a(adx_engine* e, int B, const float* x, const int64_t* t
     if (!a) return ADX_EINVAL;
     if (!x || !t || !transition || !prior || !out || (a->cfg.map_cond && !maps)) { set_error("denoise_a: null pointer"); return ADX_EINVAL; }
     return a->denoise(B, x, t, maps, transition, prior, out, (hipStream_t)stream);
+}
+
+ADX_API int adx_debug_stage_a(adx_engine* e, int B, int stage, int iters, void* stream) {
+    EngineA* a = as_a(e, "debug_stage_a");
+    if (!a) return ADX_EINVAL;
+    return a->debug_stage(B, stage, iters, (hipStream_t)stream);
 }
 
 ADX_API int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transition, const float* prior, const float* noise,

@@ -23,6 +23,7 @@
 #include "adx_ops.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace adx {
 
@@ -98,19 +99,17 @@ __device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, con
         const unsigned short* wlo = whi + NFRAG_BF * 64 * 8;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            u16x8 bh, bl;
+            bf16x8 bhv, blv;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = in[8 * s + j];
-                const unsigned short hi = f2bf_(v);
-                bh[j] = hi;
-                bl[j] = f2bf_(v - bf2f_(hi));
+                const __bf16 hi = (__bf16)v;              // v_cvt_pk_bf16_f32, round to nearest even
+                bhv[j] = hi;
+                blv[j] = (__bf16)(v - (float)hi);
             }
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(whi + s * 64 * 8);
-            const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh);
             if constexpr (PREC == PREC_BF16X3) {
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(wlo + s * 64 * 8);
-                const bf16x8 blv = __builtin_bit_cast(bf16x8, bl);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blv, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhv, acc, 0, 0, 0);
             }
@@ -162,38 +161,52 @@ __device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gam
     return o;
 }
 
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
+// Inputs of one row, as the lane that owns (row, half h) needs them.
+struct RowIn {
+    float4 x[4];      // x0 features 8g + 4h .. +3
+    float4 q[4];      // layer-0 query of heads 2g + h
+    float4 st[6];     // softmax states of heads 2g + h: 4 x {m, l, o0..o3}, contiguous
+};
+
+__device__ __forceinline__ void load_row(RowIn& in, const EncRowsArgs& a, int64_t row, int h) {
+    const float* xp = a.x0 + row * D + 4 * h;
+    const float* qp = a.q + row * a.ldq + 4 * h;
+    const float4* sp = reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        in.x[g] = *reinterpret_cast<const float4*>(xp + 8 * g);
+        in.q[g] = *reinterpret_cast<const float4*>(qp + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in.st[i] = sp[i];
+}
+
+template <int PREC, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* img = smem;                                                  // 49152 B
-    float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats
+    float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats, then k0 (scaled) and v0
+    const float sc = a.scale * LOG2E_F;
     {
         const uint4* src = reinterpret_cast<const uint4*>(PREC == PREC_F32 ? (const void*)a.img_f32 : (const void*)a.img_bf);
         uint4* dst = reinterpret_cast<uint4*>(img);
         for (int i = threadIdx.x; i < IMG_F32_FLOATS / 4; i += 256) dst[i] = src[i];
         for (int i = threadIdx.x; i < VEC_FLOATS; i += 256) vec[i] = a.vecs[i];
+        if (threadIdx.x < 64) vec[VEC_FLOATS + threadIdx.x] = a.key0[threadIdx.x] * (threadIdx.x < 32 ? sc : 1.0f);
     }
     __syncthreads();
     const float *bo = vec, *g2 = vec + 32, *be2 = vec + 64, *b2 = vec + 96, *g1 = vec + 128, *be1 = vec + 160, *b1 = vec + 192,
-                *bkv = vec + 320, *bq = vec + 384;
+                *bkv = vec + 320, *bq = vec + 384, *k0s = vec + VEC_FLOATS, *v0s = vec + VEC_FLOATS + 32;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     const int64_t n_rows = (int64_t)a.B * a.L;
-    const float sc = a.scale * LOG2E_F;
-    // time-token key / value of this lane's four heads (head = 2g + h)
-    float k0[4][4], v0[4][4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float4 kk = *reinterpret_cast<const float4*>(a.key0 + (2 * g + h) * 4);
-        const float4 vv = *reinterpret_cast<const float4*>(a.key0 + D + (2 * g + h) * 4);
-        k0[g][0] = kk.x * sc; k0[g][1] = kk.y * sc; k0[g][2] = kk.z * sc; k0[g][3] = kk.w * sc;
-        v0[g][0] = vv.x; v0[g][1] = vv.y; v0[g][2] = vv.z; v0[g][3] = vv.w;
-    }
 
     for (int64_t tile0 = (int64_t)wave_global * 32; tile0 < n_rows; tile0 += (int64_t)n_waves * 32) {
         const int64_t row = min(tile0 + c, n_rows - 1);          // clamp: out-of-range lanes recompute the last row, never store
         const bool live = tile0 + c < n_rows;
-        const int r = (int)(row % a.L);
+        const int r = (int)((unsigned)row % (unsigned)a.L);      // B * L < 2^31 is checked by the launcher
+        RowIn in;
+        load_row(in, a, row, h);
         // ---- attention output of layer 0 in accumulator layout: register 4g+i <-> feature 8g + 4h + i
         f32x16 att;
         if (r == 0) {
@@ -204,35 +217,30 @@ __global__ __launch_bounds__(256, 2) void enc_rows_kernel(const EncRowsArgs a) {
                 att[4 * g] = t.x; att[4 * g + 1] = t.y; att[4 * g + 2] = t.z; att[4 * g + 3] = t.w;
             }
         } else {
-            const float* qp = a.q + row * a.ldq;
-            const float* sp = a.state + row * (NH * 6);
+            const float* stf = reinterpret_cast<const float*>(in.st);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int hd = 2 * g + h;
-                const float4 q = *reinterpret_cast<const float4*>(qp + hd * 4);
-                const float2 ml = *reinterpret_cast<const float2*>(sp + hd * 6);
-                const float2 o01 = *reinterpret_cast<const float2*>(sp + hd * 6 + 2);
-                const float2 o23 = *reinterpret_cast<const float2*>(sp + hd * 6 + 4);
-                const float s = fmaf(q.x, k0[g][0], fmaf(q.y, k0[g][1], fmaf(q.z, k0[g][2], q.w * k0[g][3])));
-                const float mn = fmaxf(ml.x, s);
-                const float al = exp2f(ml.x - mn), p = exp2f(s - mn);
-                const float inv = __frcp_rn(fmaf(ml.y, al, p));
-                att[4 * g + 0] = fmaf(o01.x, al, p * v0[g][0]) * inv;
-                att[4 * g + 1] = fmaf(o01.y, al, p * v0[g][1]) * inv;
-                att[4 * g + 2] = fmaf(o23.x, al, p * v0[g][2]) * inv;
-                att[4 * g + 3] = fmaf(o23.y, al, p * v0[g][3]) * inv;
+                const float4 q = in.q[g];
+                const float4 kk = *reinterpret_cast<const float4*>(k0s + 8 * g + 4 * h);
+                const float4 vv = *reinterpret_cast<const float4*>(v0s + 8 * g + 4 * h);
+                const float m0 = stf[6 * g], l0 = stf[6 * g + 1];
+                const float s = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+                const float mn = fmaxf(m0, s);
+                const float al = exp2f(m0 - mn), p = exp2f(s - mn);
+                const float inv = __frcp_rn(fmaf(l0, al, p));
+                att[4 * g + 0] = fmaf(stf[6 * g + 2], al, p * vv.x) * inv;
+                att[4 * g + 1] = fmaf(stf[6 * g + 3], al, p * vv.y) * inv;
+                att[4 * g + 2] = fmaf(stf[6 * g + 4], al, p * vv.z) * inv;
+                att[4 * g + 3] = fmaf(stf[6 * g + 5], al, p * vv.w) * inv;
             }
         }
         // ---- y1 = x0 + Wo att + bo
         f32x16 y1 = mm<PREC>(img, tile_base(0), att, zero16(), lane);
-        {
-            const float* xp = a.x0 + row * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 x = *reinterpret_cast<const float4*>(xp + 8 * g + 4 * h);
-                const float4 b = *reinterpret_cast<const float4*>(bo + 8 * g + 4 * h);
-                y1[4 * g + 0] += x.x + b.x; y1[4 * g + 1] += x.y + b.y; y1[4 * g + 2] += x.z + b.z; y1[4 * g + 3] += x.w + b.w;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const float4 x = in.x[g];
+            const float4 b = *reinterpret_cast<const float4*>(bo + 8 * g + 4 * h);
+            y1[4 * g + 0] += x.x + b.x; y1[4 * g + 1] += x.y + b.y; y1[4 * g + 2] += x.z + b.z; y1[4 * g + 3] += x.w + b.w;
         }
         // ---- y2 = y1 + W2 gelu(W1 LN(y1) + b1) + b2, one 32-wide slice of the hidden layer at a time
         const f32x16 hn = layer_norm32(y1, g2, be2, h);
@@ -303,17 +311,25 @@ hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W
 }
 
 hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
-    if (a0.B <= 0 || a0.L <= 0 || !a0.image) return hipErrorInvalidValue;
+    if (a0.B <= 0 || a0.L <= 0 || !a0.image || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
     EncRowsArgs a = a0;
     a.img_f32 = reinterpret_cast<const float*>(a.image);
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
-    const size_t smem = IMG_F32_FLOATS * 4 + VEC_FLOATS * 4;
+    const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 64) * 4;
     const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32;
+    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 3; }();   // tuning knob: 3 spills a little but hides more latency
     int blocks = (int)((tiles + 3) / 4);
-    if (blocks > 512) blocks = 512;            // 2 workgroups per CU; waves stride over the remaining tiles
-    if (prec == PREC_F32) hipLaunchKernelGGL(enc_rows_kernel<PREC_F32>, dim3(blocks), dim3(256), smem, stream, a);
-    else if (prec == PREC_BF16) hipLaunchKernelGGL(enc_rows_kernel<PREC_BF16>, dim3(blocks), dim3(256), smem, stream, a);
-    else hipLaunchKernelGGL(enc_rows_kernel<PREC_BF16X3>, dim3(blocks), dim3(256), smem, stream, a);
+    const int cap = 256 * (waves == 3 ? 3 : 2);        // resident workgroups; waves stride over the remaining tiles
+    if (blocks > cap) blocks = cap;
+#define ADX_LAUNCH_ROWS(P)                                                                                     \
+    do {                                                                                                       \
+        if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3>), dim3(blocks), dim3(256), smem, stream, a); \
+        else hipLaunchKernelGGL((enc_rows_kernel<P, 2>), dim3(blocks), dim3(256), smem, stream, a);            \
+    } while (0)
+    if (prec == PREC_F32) ADX_LAUNCH_ROWS(PREC_F32);
+    else if (prec == PREC_BF16) ADX_LAUNCH_ROWS(PREC_BF16);
+    else ADX_LAUNCH_ROWS(PREC_BF16X3);
+#undef ADX_LAUNCH_ROWS
     return hipGetLastError();
 }
 

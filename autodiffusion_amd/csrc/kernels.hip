@@ -371,7 +371,10 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttentionArgs a) 
     }
     if (qok) {
         if (a.state) {
-            float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)q * a.state_ld + h * (2 + DH);
+            // heads are stored even ones first, then odd ones: the fused row kernel gives lane half 0 / 1 the even / odd
+            // heads of a row, and this makes each half's four states one contiguous 96-byte run
+            float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)q * a.state_ld +
+                        ((h & 1) * (a.H / 2) + (h >> 1)) * (2 + DH);
             Sp[0] = m; Sp[1] = l;
 #pragma unroll
             for (int c = 0; c < DH; ++c) Sp[2 + c] = o[c];
@@ -471,10 +474,77 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
     }
 }
 
+// Variant for up to 12 queries: wave w owns queries 3w..3w+2 and scans ALL keys (8 heads x 8 key lanes), so a thread
+// holds three softmax states instead of twelve -- four times the resident waves to hide the K/V load latency; the
+// four waves read the same key rows, which the L1/L2 serve after the first touch.
+__global__ __launch_bounds__(256) void attn_fewq3_kernel(const AttentionArgs a) {
+    constexpr int DH = 4, NQ = 3;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane & 7, kl = lane >> 3;
+    const int q0 = blockIdx.x * 12 + wave * NQ;
+    float qv[NQ][DH], m[NQ], l[NQ], o[NQ][DH];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int q = min(q0 + i, a.Sq - 1);
+        const float4 t = *reinterpret_cast<const float4*>(a.Q + (int64_t)b * a.q_batch_stride + (int64_t)q * a.ldq + h * DH);
+        const float f = a.scale * LOG2E;
+        qv[i][0] = t.x * f; qv[i][1] = t.y * f; qv[i][2] = t.z * f; qv[i][3] = t.w * f;
+        m[i] = -INFINITY; l[i] = 0.f;
+        o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
+    }
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + h * DH;
+    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + h * DH;
+    // software pipeline: the next key's K/V are in flight while this one is processed
+    float4 kn = make_float4(0.f, 0.f, 0.f, 0.f), vn = kn;
+    if (kl < a.Skv) {
+        kn = *reinterpret_cast<const float4*>(Kb + (int64_t)kl * a.ldk);
+        vn = *reinterpret_cast<const float4*>(Vb + (int64_t)kl * a.ldv);
+    }
+    for (int j = kl; j < a.Skv; j += 8) {
+        const float4 kk = kn, vv = vn;
+        if (j + 8 < a.Skv) {
+            kn = *reinterpret_cast<const float4*>(Kb + (int64_t)(j + 8) * a.ldk);
+            vn = *reinterpret_cast<const float4*>(Vb + (int64_t)(j + 8) * a.ldv);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
+            const float mn = fmaxf(m[i], s);
+            const float al = exp2f(m[i] - mn), p = exp2f(s - mn);
+            l[i] = fmaf(l[i], al, p);
+            o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
+            o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
+            m[i] = mn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[i], off, 64), l2 = __shfl_xor(l[i], off, 64);
+            const float o0 = __shfl_xor(o[i][0], off, 64), o1 = __shfl_xor(o[i][1], off, 64);
+            const float o2 = __shfl_xor(o[i][2], off, 64), o3 = __shfl_xor(o[i][3], off, 64);
+            const float mn = fmaxf(m[i], m2);
+            const float a1 = mn == -INFINITY ? 0.f : exp2f(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2f(m2 - mn);
+            l[i] = l[i] * a1 + l2 * a2;
+            o[i][0] = o[i][0] * a1 + o0 * a2; o[i][1] = o[i][1] * a1 + o1 * a2;
+            o[i][2] = o[i][2] * a1 + o2 * a2; o[i][3] = o[i][3] * a1 + o3 * a2;
+            m[i] = mn;
+        }
+        if (lane < 8 && q0 + i < a.Sq) {
+            const float inv = 1.f / l[i];
+            float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)(q0 + i) * a.ldo + lane * DH;
+            *reinterpret_cast<float4*>(Op) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+        }
+    }
+}
+
 hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream) {
     if (a.B <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.H != 8 || a.dh != 4 || a.dv != 4 || a.mask_off >= 0) return hipErrorInvalidValue;
     if (a.Sq == 1) hipLaunchKernelGGL(attn_fewq_kernel<1>, dim3(1, a.B), dim3(256), 0, stream, a);
     else if (a.Sq <= 4) hipLaunchKernelGGL(attn_fewq_kernel<4>, dim3(1, a.B), dim3(256), 0, stream, a);
+    else if (!a.key0) hipLaunchKernelGGL(attn_fewq3_kernel, dim3((a.Sq + 11) / 12, a.B), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fewq_kernel<12>, dim3((a.Sq + 11) / 12, a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
@@ -491,7 +561,8 @@ __global__ __launch_bounds__(256) void attn_merge_key_kernel(const AttentionArgs
     const float4 q = *reinterpret_cast<const float4*>(a.Q + (int64_t)b * a.q_batch_stride + (int64_t)r * a.ldq + h * DH);
     const float4 k = *reinterpret_cast<const float4*>(a.key0 + h * DH);
     const float4 v = *reinterpret_cast<const float4*>(a.key0 + a.H * DH + h * DH);
-    const float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)r * a.state_ld + h * (2 + DH);
+    const float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)r * a.state_ld +
+                      ((h & 1) * (a.H / 2) + (h >> 1)) * (2 + DH);
     const float m = Sp[0], l = Sp[1];
     const float s = (q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w) * (a.scale * LOG2E);
     const float mn = fmaxf(m, s);

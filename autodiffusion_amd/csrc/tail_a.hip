@@ -40,14 +40,20 @@ __device__ __forceinline__ void gemm_g(const float* X, int ldx, const float* w, 
 #pragma unroll
         for (int i = 0; i < RPT; ++i) acc[i] = 0.f;
         const float4* wp = reinterpret_cast<const float4*>(w + m.w_off) + n;
-        for (int k4 = 0; k4 < m.K / 4; ++k4) {
-            const float4 wv = wp[(int64_t)k4 * m.N];
+        // weights come from L2: fetch eight k-steps (32 k) at a time so their latencies overlap
+        for (int k0 = 0; k0 < m.K / 4; k0 += 8) {
+            float4 wv[8];
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int t = rg + i * G;
-                if (t < TRM) {
-                    const float4 xv = *reinterpret_cast<const float4*>(X + t * ldx + 4 * k4);
-                    acc[i] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[i]))));
+            for (int u = 0; u < 8; ++u) wv[u] = (k0 + u < m.K / 4) ? wp[(int64_t)(k0 + u) * m.N] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int t = rg + i * G;
+                    if (t < TRM) {
+                        const float4 xv = *reinterpret_cast<const float4*>(X + t * ldx + 4 * min(k0 + u, m.K / 4 - 1));
+                        acc[i] = fmaf(wv[u].x, xv.x, fmaf(wv[u].y, xv.y, fmaf(wv[u].z, xv.z, fmaf(wv[u].w, xv.w, acc[i]))));
+                    }
                 }
             }
         }

@@ -112,6 +112,10 @@ class Engine:
                                       flags, current_stream()), "adx_generate_a")
         return out
 
+    def debug_stage_a(self, batch: int, stage: int, iters: int = 1):
+        """Launch one kernel stage of a variant-A step on the current workspace (timing aid)."""
+        check(self.lib.adx_debug_stage_a(self.h, int(batch), int(stage), int(iters), current_stream()), "adx_debug_stage_a")
+
     def sample_dit(self, state, noise, flags: int, out: Optional[torch.Tensor] = None):
         B, S = state.shape[0], state.shape[1]
         n_noise = 0 if noise is None else noise.shape[0]

@@ -164,6 +164,12 @@ int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transitio
 int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
                    const float* init_x, const float* noise, int n_noise, float* out, unsigned flags, void* stream);
 
+/* No counterpart in the reference: launches ONE kernel stage of a variant-A sampling step `iters` times on the
+ * engine's current workspace (after a generate/sample call with the same B), so a benchmark can time that kernel
+ * alone with events on `stream`.  stage: 0 time-token attention, 1 fused encoder rows, 2 last-layer attention,
+ * 3 fused tail, 4 per-chunk attention-state build. */
+int adx_debug_stage_a(adx_engine* e, int B, int stage, int iters, void* stream);
+
 /* DiffusionWrapper.sample_forward / p_sample_loop -- models/diffusion_loss/diffusion_decoder.py:377-446.
  * state[B][S][d_model]; noise[n_noise][B][S][4] (may be NULL with ADX_FLAG_INIT_ZERO and a noise-free
  * schedule); out[B][S][4] is de-normalised when ADX_FLAG_NORMALIZE is set. */
