@@ -87,9 +87,10 @@ hipError_t attention_merge_key(const AttentionArgs& a, hipStream_t stream);
 // then layer 1's LayerNorm and K/V projection.  Rows r < n_keep of every item also store the layer-1 residual input
 // (x1) and its normalised copy (h1).
 struct EncRowsArgs {
-    const float* x0 = nullptr;                       // [B*L][32] encoder input rows
-    const float* q = nullptr; int64_t ldq = 0;       // layer-0 queries, row stride ldq
-    const float* state = nullptr;                    // [B*L][8][6] {m, l, o[4]}
+    const float* x0 = nullptr;                       // [B*L][32] encoder input rows (enc_rows reads row 0 of each item only)
+    const float* q = nullptr; int64_t ldq = 0;       // layer-0 queries, row stride ldq           } read by enc_rows_pack,
+    const float* state = nullptr;                    // [B*L][8][6] {m, l, o[4]}                  } not by enc_rows
+    const float4* packed = nullptr;                  // x0, q, state of every row in lane order (enc_rows_packed_bytes)
     const float* att0 = nullptr;                     // [B*L][32], only row 0 of each item is read
     const float* key0 = nullptr;                     // [64]
     const void* image = nullptr;                     // weight fragment image from enc_rows_build_image
@@ -104,7 +105,9 @@ struct EncRowsArgs {
 size_t enc_rows_image_bytes();
 hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, const float* Wq, void* image,
                                 hipStream_t stream);
-hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);
+size_t enc_rows_packed_bytes(int B, int L);
+hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream);      // once per chunk: x0/q/state -> packed
+hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);  // once per step
 
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
 hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);

@@ -42,7 +42,7 @@ struct EngineA final : adx_engine {
     // elide level 2: layer-0 attention cache.  QKV0: in_proj(LN1(X0)) of every conditioning row, valid for a whole chunk
     // (rows >= 1 do not depend on the diffusion step); ST: softmax state of every query row >= 1 over key rows >= 1;
     // tqkv0: per-step q/k/v of the time token (identical for every batch item), [n_steps][3d].
-    float *QKV0 = nullptr, *ST = nullptr, *tqkv0 = nullptr;
+    float *QKV0 = nullptr, *ST = nullptr, *PK = nullptr, *tqkv0 = nullptr;
     bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
     // elide level 3: the per-row pipeline between the two encoder attentions runs as one fused kernel
     bool fused = false;
@@ -119,6 +119,7 @@ struct EngineA final : adx_engine {
         take(&TRAW, (size_t)B * NP * Cp); take(&PRAW, (size_t)B * NP * Cp); take(&CHO, BT * Cin);
         take(&TE, (size_t)B * d);
         if (cfg.elide >= 2) { take(&QKV0, BL * 3 * d); take(&ST, BL * H * 6); }
+        if (fused) take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
         *bytes = off;
         return ADX_OK;
     }
@@ -230,7 +231,18 @@ struct EngineA final : adx_engine {
         at.B = B; at.H = H; at.Sq = L - 1; at.Skv = L - 1; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
         at.state = ST + H * 6; at.state_ld = H * 6; at.state_batch_stride = (int64_t)L * H * 6;
         ADX_HIP(attention(at, s));
+        if (fused) ADX_HIP(enc_rows_pack(rows_args(B, nullptr), s));
         return ADX_OK;
+    }
+
+    EncRowsArgs rows_args(int B, const float* tq) const {
+        EncRowsArgs r;
+        r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.packed = reinterpret_cast<const float4*>(PK);
+        r.att0 = ATT; r.key0 = tq ? tq + d : nullptr;
+        r.image = rows_image; r.vecs = rows_vecs;
+        r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
+        r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
+        return r;
     }
 
     // ---------------------------------------------------------------------------------- conditioning rows
@@ -307,12 +319,7 @@ struct EngineA final : adx_engine {
             // layer 0 and layer 1 up to its attention: three launches
             ADX_TRY(time_token_attention(B, step, s));
             const float* tq = tqkv0 + (int64_t)step * 3 * d;
-            EncRowsArgs r;
-            r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.att0 = ATT; r.key0 = tq + d;
-            r.image = rows_image; r.vecs = rows_vecs;
-            r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
-            r.B = B; r.L = L; r.n_keep = T + 1; r.scale = scale;
-            ADX_HIP(enc_rows(r, cfg.precision, s));
+            ADX_HIP(enc_rows(rows_args(B, tq), cfg.precision, s));
             ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
             if (tail_ok && io.x_next && stepped) {
                 TailArgs t = tail_tpl;
@@ -425,18 +432,11 @@ struct EngineA final : adx_engine {
     // 3 fused tail, 4 per-chunk cache build.  Needs a previous generate/sample call with the same B.
     int debug_stage(int B, int stage, int iters, hipStream_t s) {
         if (!finalized || steps.empty() || B > max_batch || !fused) { set_error("debug_stage: engine not ready (needs elide 3, a schedule and a prior call)"); return ADX_ESTATE; }
-        const int dh = d / H;
-        const float scale = 1.0f / sqrtf((float)dh);
         const float* tq = tqkv0;
         for (int it = 0; it < iters; ++it) {
             if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
             else if (stage == 1) {
-                EncRowsArgs r;
-                r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.att0 = ATT; r.key0 = tq + d;
-                r.image = rows_image; r.vecs = rows_vecs;
-                r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
-                r.B = B; r.L = L; r.n_keep = T + 1; r.scale = scale;
-                ADX_HIP(enc_rows(r, cfg.precision, s));
+                ADX_HIP(enc_rows(rows_args(B, tq), cfg.precision, s));
             } else if (stage == 2) ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
             else if (stage == 3) {
                 if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }

@@ -21,6 +21,7 @@
 //
 // HBM traffic per row and step (f32): read x0 128 B, q 128 B, softmax state 192 B; write k/v 256 B  -> 704 B.
 #include "adx_ops.h"
+#include "fastmath.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -119,15 +120,15 @@ __device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, con
     return acc;
 }
 
-// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one reciprocal, one exponential, five fma
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+// GELU(v) = v Phi(v) with erfc(|x|), x = v / sqrt(2), from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7):
+// erfc(|x|) = t (a1 + t (a2 + ...)) exp(-x^2), t = 1 / (1 + p |x|);  v Phi(v) = v - v erfc/2 for v > 0, v erfc/2 otherwise.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float ax = fabsf(v) * 0.70710678118654752f;
+    const float t = rcp_fast(fmaf(0.3275911f, ax, 1.0f));
     const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float r = 1.0f - p * exp2f(-ax * ax * LOG2E_F);
-    return copysignf(r, x);
+    const float hr = 0.5f * v * p * exp2_fast(-LOG2E_F * ax * ax);
+    return v > 0.f ? v - hr : hr;
 }
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f)); }
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -147,7 +148,7 @@ __device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gam
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const float t = y[i] - mean; q = fmaf(t, t, q); }
     q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + 1e-5f);
+    const float rstd = rsqrt_fast(fmaf(q, 1.0f / 32.0f, 1e-5f));
     f32x16 o;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -167,18 +168,33 @@ struct RowIn {
     float4 q[4];      // layer-0 query of heads 2g + h
     float4 st[6];     // softmax states of heads 2g + h: 4 x {m, l, o0..o3}, contiguous
 };
+constexpr int PACK_VECS = 14;   // float4 per lane per 32-row tile: exactly the 448 B a row contributes
 
-__device__ __forceinline__ void load_row(RowIn& in, const EncRowsArgs& a, int64_t row, int h) {
-    const float* xp = a.x0 + row * D + 4 * h;
-    const float* qp = a.q + row * a.ldq + 4 * h;
-    const float4* sp = reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24);
+// The step-independent inputs of a tile are re-read on every diffusion step, so they are stored once per chunk in the
+// order the lanes consume them: packed[(tile * 14 + j) * 64 + lane].  Every load instruction of the row kernel then
+// covers 1 KB of contiguous memory (eight full 128-B lines) instead of 32 B out of each of 32 lines.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, float4* __restrict__ packed, int64_t n_tiles) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_tiles * PACK_VECS * 64) return;
+    const int lane = (int)(i & 63), j = (int)((i >> 6) % PACK_VECS);
+    const int64_t tile = (i >> 6) / PACK_VECS;
+    const int64_t n_rows = (int64_t)a.B * a.L;
+    const int64_t row = min(tile * 32 + (lane & 31), n_rows - 1);
+    const int h = lane >> 5;
+    float4 v;
+    if (j < 4) v = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * j);
+    else if (j < 8) v = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * (j - 4));
+    else v = *reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24 + 4 * (j - 8));
+    packed[i] = v;
+}
+
+__device__ __forceinline__ void load_row(RowIn& in, const float4* __restrict__ p) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        in.x[g] = *reinterpret_cast<const float4*>(xp + 8 * g);
-        in.q[g] = *reinterpret_cast<const float4*>(qp + 8 * g);
-    }
+    for (int g = 0; g < 4; ++g) in.x[g] = p[64 * g];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) in.st[i] = sp[i];
+    for (int g = 0; g < 4; ++g) in.q[g] = p[64 * (4 + g)];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in.st[i] = p[64 * (8 + i)];
 }
 
 template <int PREC, int WAVES>
@@ -206,15 +222,17 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
         const bool live = tile0 + c < n_rows;
         const int r = (int)((unsigned)row % (unsigned)a.L);      // B * L < 2^31 is checked by the launcher
         RowIn in;
-        load_row(in, a, row, h);
+        load_row(in, a.packed + (tile0 >> 5) * (PACK_VECS * 64) + lane);
         // ---- attention output of layer 0 in accumulator layout: register 4g+i <-> feature 8g + 4h + i
         f32x16 att;
-        if (r == 0) {
+        if (r == 0) {                                           // the time token changes every step: read it in place
             const float* ap = a.att0 + row * D;
+            const float* xp = a.x0 + row * D;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t = *reinterpret_cast<const float4*>(ap + 8 * g + 4 * h);
                 att[4 * g] = t.x; att[4 * g + 1] = t.y; att[4 * g + 2] = t.z; att[4 * g + 3] = t.w;
+                in.x[g] = *reinterpret_cast<const float4*>(xp + 8 * g + 4 * h);
             }
         } else {
             const float* stf = reinterpret_cast<const float*>(in.st);
@@ -226,8 +244,8 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
                 const float m0 = stf[6 * g], l0 = stf[6 * g + 1];
                 const float s = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
                 const float mn = fmaxf(m0, s);
-                const float al = exp2f(m0 - mn), p = exp2f(s - mn);
-                const float inv = __frcp_rn(fmaf(l0, al, p));
+                const float al = exp2_fast(m0 - mn), p = exp2_fast(s - mn);
+                const float inv = rcp_fast(fmaf(l0, al, p));
                 att[4 * g + 0] = fmaf(stf[6 * g + 2], al, p * vv.x) * inv;
                 att[4 * g + 1] = fmaf(stf[6 * g + 3], al, p * vv.y) * inv;
                 att[4 * g + 2] = fmaf(stf[6 * g + 4], al, p * vv.z) * inv;
@@ -310,14 +328,23 @@ hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W
     return hipGetLastError();
 }
 
+size_t enc_rows_packed_bytes(int B, int L) { return (size_t)(((int64_t)B * L + 31) / 32) * PACK_VECS * 64 * sizeof(float4); }
+
+hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.L <= 0 || !a.packed || !a.x0 || !a.q || !a.state) return hipErrorInvalidValue;
+    const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32, n = tiles * PACK_VECS * 64;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, const_cast<float4*>(a.packed), tiles);
+    return hipGetLastError();
+}
+
 hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
-    if (a0.B <= 0 || a0.L <= 0 || !a0.image || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    if (a0.B <= 0 || a0.L <= 0 || !a0.image || !a0.packed || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
     EncRowsArgs a = a0;
     a.img_f32 = reinterpret_cast<const float*>(a.image);
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
     const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 64) * 4;
     const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32;
-    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 3; }();   // tuning knob: 3 spills a little but hides more latency
+    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 2; }();   // tuning knob: 3 waves per SIMD spills, and the spills reach HBM
     int blocks = (int)((tiles + 3) / 4);
     const int cap = 256 * (waves == 3 ? 3 : 2);        // resident workgroups; waves stride over the remaining tiles
     if (blocks > cap) blocks = cap;

@@ -1,6 +1,7 @@
 // HIP kernels for the trajectory-diffusion sampling path, written for gfx950 (CDNA4):
 // 64-lane wavefronts, MFMA matrix instructions, LDS-staged tiles.
 #include "adx_ops.h"
+#include "fastmath.h"
 
 #include <math.h>
 
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormArgs a) {
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
     for (int c = lane; c < d; c += 64) { float t = x[c] - mean; q += t * t; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + a.eps);
+    const float rstd = rsqrt_fast(wave_sum(q) / (float)d + a.eps);
     const float* sh = a.shift ? a.shift + (int64_t)row * a.ldm : nullptr;
     const float* sc = a.scale ? a.scale + (int64_t)row * a.ldm : nullptr;
     for (int c = lane; c < d; c += 64) {
@@ -354,14 +355,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttentionArgs a) 
             }
             const float mn = fmaxf(m, mx);
             if (mn == -INFINITY) continue;
-            const float alpha = exp2f(m - mn);
+            const float alpha = exp2_fast(m - mn);
             l *= alpha;
 #pragma unroll
             for (int c = 0; c < DH; ++c) o[c] *= alpha;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = min(jj + u, nk - 1);
-                const float p = exp2f(s[u] - mn);
+                const float p = exp2_fast(s[u] - mn);
                 l += p;
 #pragma unroll
                 for (int c = 0; c < DH; ++c) o[c] = fmaf(p, Vs[j * DH + c], o[c]);
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttentionArgs a) 
             for (int c = 0; c < DH; ++c) Sp[2 + c] = o[c];
         } else {
             float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + h * DH;
-            const float inv = 1.f / l;
+            const float inv = rcp_fast(l);
 #pragma unroll
             for (int c = 0; c < DH; ++c) Op[c] = o[c] * inv;
         }
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
         for (int i = 0; i < NQ; ++i) {
             const float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
             const float mn = fmaxf(m[i], s);
-            const float al = exp2f(m[i] - mn), p = exp2f(s - mn);
+            const float al = exp2_fast(m[i] - mn), p = exp2_fast(s - mn);
             l[i] = fmaf(l[i], al, p);
             o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
             o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
             const float o0 = __shfl_xor(o[i][0], off, 64), o1 = __shfl_xor(o[i][1], off, 64);
             const float o2 = __shfl_xor(o[i][2], off, 64), o3 = __shfl_xor(o[i][3], off, 64);
             const float mn = fmaxf(m[i], m2);
-            const float a1 = mn == -INFINITY ? 0.f : exp2f(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2f(m2 - mn);
+            const float a1 = mn == -INFINITY ? 0.f : exp2_fast(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2_fast(m2 - mn);
             l[i] = l[i] * a1 + l2 * a2;
             o[i][0] = o[i][0] * a1 + o0 * a2; o[i][1] = o[i][1] * a1 + o1 * a2;
             o[i][2] = o[i][2] * a1 + o2 * a2; o[i][3] = o[i][3] * a1 + o3 * a2;
@@ -462,12 +463,12 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const float* r = red[w][hh][i];
-                const float al = r[0] == -INFINITY ? 0.f : exp2f(r[0] - mn);
+                const float al = r[0] == -INFINITY ? 0.f : exp2_fast(r[0] - mn);
                 ls += r[1] * al;
 #pragma unroll
                 for (int c = 0; c < DH; ++c) os[c] += r[2 + c] * al;
             }
-            const float inv = 1.f / ls;
+            const float inv = rcp_fast(ls);
             float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)(q0 + i) * a.ldo + hh * DH;
             *reinterpret_cast<float4*>(Op) = make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
         }
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_fewq3_kernel(const AttentionArgs a) 
         for (int i = 0; i < NQ; ++i) {
             const float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
             const float mn = fmaxf(m[i], s);
-            const float al = exp2f(m[i] - mn), p = exp2f(s - mn);
+            const float al = exp2_fast(m[i] - mn), p = exp2_fast(s - mn);
             l[i] = fmaf(l[i], al, p);
             o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
             o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
@@ -526,14 +527,14 @@ __global__ __launch_bounds__(256) void attn_fewq3_kernel(const AttentionArgs a) 
             const float o0 = __shfl_xor(o[i][0], off, 64), o1 = __shfl_xor(o[i][1], off, 64);
             const float o2 = __shfl_xor(o[i][2], off, 64), o3 = __shfl_xor(o[i][3], off, 64);
             const float mn = fmaxf(m[i], m2);
-            const float a1 = mn == -INFINITY ? 0.f : exp2f(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2f(m2 - mn);
+            const float a1 = mn == -INFINITY ? 0.f : exp2_fast(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2_fast(m2 - mn);
             l[i] = l[i] * a1 + l2 * a2;
             o[i][0] = o[i][0] * a1 + o0 * a2; o[i][1] = o[i][1] * a1 + o1 * a2;
             o[i][2] = o[i][2] * a1 + o2 * a2; o[i][3] = o[i][3] * a1 + o3 * a2;
             m[i] = mn;
         }
         if (lane < 8 && q0 + i < a.Sq) {
-            const float inv = 1.f / l[i];
+            const float inv = rcp_fast(l[i]);
             float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)(q0 + i) * a.ldo + lane * DH;
             *reinterpret_cast<float4*>(Op) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
         }
@@ -566,8 +567,8 @@ __global__ __launch_bounds__(256) void attn_merge_key_kernel(const AttentionArgs
     const float m = Sp[0], l = Sp[1];
     const float s = (q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w) * (a.scale * LOG2E);
     const float mn = fmaxf(m, s);
-    const float al = exp2f(m - mn), p = exp2f(s - mn);
-    const float inv = 1.f / fmaf(l, al, p);
+    const float al = exp2_fast(m - mn), p = exp2_fast(s - mn);
+    const float inv = rcp_fast(fmaf(l, al, p));
     float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)r * a.ldo + h * DH;
     *reinterpret_cast<float4*>(Op) = make_float4(fmaf(Sp[2], al, p * v.x) * inv, fmaf(Sp[3], al, p * v.y) * inv,
                                                  fmaf(Sp[4], al, p * v.z) * inv, fmaf(Sp[5], al, p * v.w) * inv);
@@ -641,10 +642,10 @@ __global__ __launch_bounds__(256) void attn_general_kernel(const AttentionArgs a
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
         float sum = 0.f;
-        for (int j = tl; j < Skv; j += 16) { float p = exp2f((row[j] - mx) * LOG2E); row[j] = p; sum += p; }
+        for (int j = tl; j < Skv; j += 16) { float p = exp2_fast((row[j] - mx) * LOG2E); row[j] = p; sum += p; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-        const float inv = 1.f / sum;
+        const float inv = rcp_fast(sum);
         for (int j = tl; j < Skv; j += 16) row[j] *= inv;
     }
     // ---- P V, value dimension in chunks of 64: thread (tq, tl) owns 4 consecutive output dims

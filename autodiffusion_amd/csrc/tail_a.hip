@@ -8,6 +8,7 @@
 // (this is the trajectory path, which stays fp32 in every precision mode), weights streamed from L2 in a
 // k-major packing ([K/4][N][4]) so that a wavefront's weight load is one contiguous 1 KiB read.
 #include "adx_ops.h"
+#include "fastmath.h"
 
 #include <math.h>
 
@@ -20,9 +21,9 @@ constexpr float LOG2E_T = 1.4426950408889634f;
 
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = rcp_fast(fmaf(0.3275911f, ax, 1.0f));
     const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float r = 1.0f - p * exp2f(-ax * ax * LOG2E_T);
+    const float r = 1.0f - p * exp2_fast(-ax * ax * LOG2E_T);
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752f)); }
@@ -92,7 +93,7 @@ __device__ __forceinline__ void layer_norm(const float* X, float* Y, const float
         float q = dlt * dlt;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 32);
-        const float rstd = 1.0f / sqrtf(q * (1.0f / 32.0f) + 1e-5f);
+        const float rstd = rsqrt_fast(fmaf(q, 1.0f / 32.0f, 1e-5f));
         Y[t * LD + f] = fmaf(dlt * rstd, w[g_off + f], w[b_off + f]);
     }
     __syncthreads();
@@ -123,13 +124,13 @@ __device__ __forceinline__ void attend(const float* Q, int ldq, const float* K, 
 #pragma unroll
         for (int j = 0; j < TRM; ++j) {
             if (j <= last) {
-                const float p = exp2f(s[j] - mx);
+                const float p = exp2_fast(s[j] - mx);
                 const float4 vv = *reinterpret_cast<const float4*>(V + j * ldkv + h * DH);
                 l += p;
                 o0 = fmaf(p, vv.x, o0); o1 = fmaf(p, vv.y, o1); o2 = fmaf(p, vv.z, o2); o3 = fmaf(p, vv.w, o3);
             }
         }
-        const float inv = 1.0f / l;
+        const float inv = rcp_fast(l);
         *reinterpret_cast<float4*>(O + q * LD + h * DH) = make_float4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
     }
     __syncthreads();
