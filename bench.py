@@ -31,7 +31,6 @@ sys.path.insert(0, ROOT)
 
 FS, N_TRAIN, N_SAMPLE, L_COND, D_MODEL, N_HEAD = 10, 100, 50, 809, 32, 8
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 
 def build_model(dev, precision="bf16"):
@@ -54,36 +53,40 @@ def make_inputs(B, row0, dev):
 def time_kernel(fn, iters=20):
     """Average duration (s) of one launch, events recorded on the stream the kernel runs on."""
     for _ in range(3):
-        fn()
+        fn(1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record()
-    for _ in range(iters):
-        fn()
+    fn(iters)
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-def roofline(B, dev):
-    """Dominant kernel of the step: the encoder self-attention over all 809 conditioning tokens (head_dim 4).
+# HBM bytes of one launch of the encoder row kernel at B = 1024 from the L2 fabric-request counters (separate rocprofv3
+# --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
+# the per-row figure scales with B.  Source: profiles/r01_pmc_enc_rows.txt.
+ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (2906131 * 128 + 3360201 * 64) / (1024 * L_COND)
+ENC_ROWS_ALGO_BYTES_PER_ROW = 448 + 256      # read x0 (128) + layer-0 query (128) + softmax state (192); write layer-1 K, V (256)
 
-    Algorithmic work per launch: QK^T and PV, 2 * 2 * L^2 * d flop per scenario (d = 32 summed over heads).
-    It is a matrix-shaped contraction, so it is priced against the dense bf16 MFMA peak even though this
-    revision runs it on the vector ALUs.
+
+def roofline(da, B):
+    """Dominant kernel of a denoiser call: the fused encoder row pipeline (enc_rows_kernel), one launch per call.
+
+    It streams every conditioning row once -- 704 algorithmic bytes per row, B * 809 rows per launch -- and does
+    22.5 kflop per row on the matrix cores, so HBM bandwidth is the roof that binds (73 us at 8 TB/s against 7.5 us
+    at the dense bf16 MFMA peak).  ``stages_us`` lists the other kernels of a call, timed the same way.
     """
-    from autodiffusion_amd import ops
-    g = torch.Generator(device="cpu").manual_seed(0)
-    q = torch.randn(B, L_COND, D_MODEL, generator=g).to(dev)
-    k = torch.randn(B, L_COND, D_MODEL, generator=g).to(dev)
-    v = torch.randn(B, L_COND, D_MODEL, generator=g).to(dev)
-    dt = time_kernel(lambda: ops.attention(q, k, v, N_HEAD))
-    flops = 4.0 * L_COND * L_COND * D_MODEL * B
-    achieved = flops / dt / 1e12
-    return {"kernel": "attn_small_kernel<4> (encoder self-attention, 809x809, head_dim 4)", "bound": "mfma",
-            "achieved": round(achieved, 3), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
-            "launch_ms": round(dt * 1e3, 4), "flop_per_launch": flops}
+    eng = da.diffusion.diffusion.model.engine()
+    names = ["time_token_attention", "enc_rows", "last_layer_attention", "tail", "chunk_cache_build"]
+    t = {n: time_kernel(lambda k, i=i: eng.debug_stage_a(B, i, k), 4 if n == "chunk_cache_build" else 20) for i, n in enumerate(names)}
+    rows = B * L_COND
+    algo = float(ENC_ROWS_ALGO_BYTES_PER_ROW * rows)
+    achieved = algo / t["enc_rows"] / 1e9
+    return {"kernel": "enc_rows_kernel (encoder layer 0 tail + layer 1 K/V over all conditioning rows)", "bound": "hbm",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows), "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
+            "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()}}
 
 
 def cpu_baseline():
@@ -179,7 +182,7 @@ def main():
                                      "fp32": "f32 MFMA"}[args.precision]},
         }
         if world == 1:
-            line["roofline"] = roofline(B, dev)
+            line["roofline"] = roofline(da, B)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
