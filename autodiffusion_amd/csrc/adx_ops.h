@@ -160,6 +160,36 @@ struct TailArgs {
 hipError_t tail_pack_matrix(const float* W, int N, int K, float* out, hipStream_t stream);
 hipError_t tail_a(const TailArgs& a, hipStream_t stream);
 
+// MFMA form of the same tail (one wavefront per item, fp32 16x16x4 MFMA); see tail_mfma.hip.  in_dim = out_dim = 4,
+// T + 1 <= 16.  `image`: weight fragments in consumption order, block b (a 32x32 map) written by tail_mfma_pack_block:
+//   0 enc.out_proj | 1..8 enc FFN (W1 slice i, W2 slice i) | per decoder layer 16 blocks: self q, k, v, out_proj,
+//   cross q, memory k, v, out_proj, FFN (W1 slice i, W2 slice i); input embedding and head by tail_mfma_pack_ends.
+// `vecs`: tail_mfma_vec_floats() floats laid out per tail_mfma_vec_layout() (pos: [16][32], head_b: zero-padded to 16).
+struct TailMfmaArgs {
+    const void* image = nullptr;
+    const float* vecs = nullptr;
+    const float* att1 = nullptr;      // as in TailArgs
+    const float* x1 = nullptr;
+    const float* x = nullptr;         // [B][T][4]
+    const float* z = nullptr;
+    const StepCoef* coef = nullptr;
+    float* x_next = nullptr;
+    float* model_out = nullptr;
+    int B = 0, L = 0, T = 0, n_dec = 0;
+};
+struct TailMfmaVecLayout {
+    int e_bo, e_ln2_g, e_ln2_b, e_b1, e_b2, din_b, pos, layer0, layer_size;
+    int ln1_g, ln1_b, ln2_g, ln2_b, ln3_g, ln3_b, bqkv, bo, bq, bkv, bo2, b1, b2;      // relative to layer0 + l * layer_size
+    int lnf_g, lnf_b, head_b;
+};
+int tail_mfma_vec_floats();
+int tail_mfma_blocks(int n_dec);
+size_t tail_mfma_image_bytes(int n_dec);
+TailMfmaVecLayout tail_mfma_vec_layout();
+hipError_t tail_mfma_pack_block(const float* W, int ldw, int row0, int col0, void* image, int block, hipStream_t stream);
+hipError_t tail_mfma_pack_ends(const float* Win, const float* Whead, void* image, hipStream_t stream);
+hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream);
+
 // f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);
 // strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)

@@ -19,6 +19,8 @@
 // and trajectory coordinates rounded to 8 mantissa bits would already cost decimetres.
 #include "engine.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 using namespace adx;
@@ -52,12 +54,17 @@ struct EngineA final : adx_engine {
     bool tail_ok = false;
     float* tail_w = nullptr;
     TailArgs tail_tpl;
+    bool tail_mfma_ok = false;         // the one-wavefront-per-item MFMA form applies (in_dim = out_dim = 4)
+    void* tailm_image = nullptr;
+    float* tailm_vecs = nullptr;
 
     ~EngineA() override {
         if (tqkv0) (void)hipFree(tqkv0);
         if (rows_image) (void)hipFree(rows_image);
         if (rows_vecs) (void)hipFree(rows_vecs);
         if (tail_w) (void)hipFree(tail_w);
+        if (tailm_image) (void)hipFree(tailm_image);
+        if (tailm_vecs) (void)hipFree(tailm_vecs);
     }
 
     explicit EngineA(const adx_model_config& c) {
@@ -71,6 +78,8 @@ struct EngineA final : adx_engine {
         if (cfg.elide >= 2 && !fast4) cfg.elide = 1;
         fused = cfg.elide >= 3 && n_enc == 2;
         tail_ok = fused && T + 1 <= 12 && Cin == Cout && Cin <= 64 && (Cin % 4) == 0 && n_dec <= 4;
+        const char* no_mfma = getenv("ADX_TAIL_VALU");       // tuning knob: force the VALU form of the tail
+        tail_mfma_ok = tail_ok && Cin == 4 && !(no_mfma && no_mfma[0] == '1');
     }
 
     std::vector<ParamSpec> expected_params() const override {
@@ -162,6 +171,80 @@ struct EngineA final : adx_engine {
             ADX_HIP(hipStreamSynchronize(s));
         }
         if (tail_ok) ADX_TRY(build_tail_pack(s));
+        if (tail_mfma_ok) ADX_TRY(build_tail_mfma(s));
+        return ADX_OK;
+    }
+
+    // Weight-fragment image and vector table of the MFMA tail.
+    int build_tail_mfma(hipStream_t s) {
+        if (!tailm_image) ADX_HIP(hipMalloc(&tailm_image, tail_mfma_image_bytes(n_dec)));
+        if (!tailm_vecs) ADX_HIP(hipMalloc(&tailm_vecs, sizeof(float) * tail_mfma_vec_floats()));
+        ADX_HIP(hipMemsetAsync(tailm_image, 0, tail_mfma_image_bytes(n_dec), s));
+        ADX_HIP(hipMemsetAsync(tailm_vecs, 0, sizeof(float) * tail_mfma_vec_floats(), s));
+        const TailMfmaVecLayout v = tail_mfma_vec_layout();
+        int blk = 0;
+        auto block = [&](const std::string& w, int ldw, int row0, int col0) {
+            return tail_mfma_pack_block(P(w), ldw, row0, col0, tailm_image, blk++, s);
+        };
+        auto vec = [&](const float* src, int off, int n) {
+            return hipMemcpyAsync(tailm_vecs + off, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s);
+        };
+        auto ffn = [&](const std::string& p) {
+            for (int i = 0; i < 4; ++i) {
+                hipError_t e = block(p + ".linear1.weight", d, 32 * i, 0);
+                if (e == hipSuccess) e = block(p + ".linear2.weight", 4 * d, 0, 32 * i);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        };
+        const std::string e1 = "encoder.layers." + std::to_string(n_enc - 1);
+        ADX_HIP(block(e1 + ".self_attn.out_proj.weight", d, 0, 0));
+        ADX_HIP(ffn(e1));
+        ADX_HIP(vec(P(e1 + ".self_attn.out_proj.bias"), v.e_bo, d));
+        ADX_HIP(vec(P(e1 + ".norm2.weight"), v.e_ln2_g, d)); ADX_HIP(vec(P(e1 + ".norm2.bias"), v.e_ln2_b, d));
+        ADX_HIP(vec(P(e1 + ".linear1.bias"), v.e_b1, 4 * d)); ADX_HIP(vec(P(e1 + ".linear2.bias"), v.e_b2, d));
+        ADX_HIP(vec(P("input_emb.bias"), v.din_b, d));
+        ADX_HIP(vec(P("pos_emb"), v.pos, T * d));
+        for (int l = 0; l < n_dec; ++l) {
+            const std::string p = "decoder.layers." + std::to_string(l);
+            const int o = v.layer0 + l * v.layer_size;
+            for (int i = 0; i < 3; ++i) ADX_HIP(block(p + ".self_attn.in_proj_weight", d, 32 * i, 0));
+            ADX_HIP(block(p + ".self_attn.out_proj.weight", d, 0, 0));
+            for (int i = 0; i < 3; ++i) ADX_HIP(block(p + ".multihead_attn.in_proj_weight", d, 32 * i, 0));
+            ADX_HIP(block(p + ".multihead_attn.out_proj.weight", d, 0, 0));
+            ADX_HIP(ffn(p));
+            ADX_HIP(vec(P(p + ".norm1.weight"), o + v.ln1_g, d)); ADX_HIP(vec(P(p + ".norm1.bias"), o + v.ln1_b, d));
+            ADX_HIP(vec(P(p + ".norm2.weight"), o + v.ln2_g, d)); ADX_HIP(vec(P(p + ".norm2.bias"), o + v.ln2_b, d));
+            ADX_HIP(vec(P(p + ".norm3.weight"), o + v.ln3_g, d)); ADX_HIP(vec(P(p + ".norm3.bias"), o + v.ln3_b, d));
+            ADX_HIP(vec(P(p + ".self_attn.in_proj_bias"), o + v.bqkv, 3 * d));
+            ADX_HIP(vec(P(p + ".self_attn.out_proj.bias"), o + v.bo, d));
+            ADX_HIP(vec(P(p + ".multihead_attn.in_proj_bias"), o + v.bq, d));
+            ADX_HIP(vec(P(p + ".multihead_attn.in_proj_bias") + d, o + v.bkv, 2 * d));
+            ADX_HIP(vec(P(p + ".multihead_attn.out_proj.bias"), o + v.bo2, d));
+            ADX_HIP(vec(P(p + ".linear1.bias"), o + v.b1, 4 * d)); ADX_HIP(vec(P(p + ".linear2.bias"), o + v.b2, d));
+        }
+        ADX_HIP(vec(P("ln_f.weight"), v.lnf_g, d)); ADX_HIP(vec(P("ln_f.bias"), v.lnf_b, d));
+        ADX_HIP(vec(P("head.bias"), v.head_b, Cout));
+        ADX_HIP(tail_mfma_pack_ends(P("input_emb.weight"), P("head.weight"), tailm_image, s));
+        if (blk != tail_mfma_blocks(n_dec)) { set_error("build_tail_mfma: block count mismatch"); return ADX_ESTATE; }
+        ADX_HIP(hipStreamSynchronize(s));
+        return ADX_OK;
+    }
+
+    // Rest of the last encoder layer + decoder + head + scheduler update, one launch.
+    int launch_tail(int B, const float* x, const float* z, const StepCoef* coef, float* x_next, float* out, hipStream_t s) {
+        if (tail_mfma_ok) {
+            TailMfmaArgs t;
+            t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = z; t.coef = coef;
+            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec;
+            ADX_HIP(tail_mfma(t, s));
+            return ADX_OK;
+        }
+        TailArgs t = tail_tpl;
+        t.w = tail_w; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = z; t.coef = coef;
+        t.x_next = x_next; t.model_out = out;
+        t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
+        ADX_HIP(tail_a(t, s));
         return ADX_OK;
     }
 
@@ -322,11 +405,7 @@ struct EngineA final : adx_engine {
             ADX_HIP(enc_rows(rows_args(B, tq), cfg.precision, s));
             ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
             if (tail_ok && io.x_next && stepped) {
-                TailArgs t = tail_tpl;
-                t.w = tail_w; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = io.z; t.coef = steps_dev + step;
-                t.x_next = io.x_next; t.model_out = out;
-                t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
-                ADX_HIP(tail_a(t, s));
+                ADX_TRY(launch_tail(B, x, io.z, steps_dev + step, io.x_next, out, s));
                 *stepped = true;
                 return ADX_OK;
             }
@@ -440,11 +519,7 @@ struct EngineA final : adx_engine {
             } else if (stage == 2) ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
             else if (stage == 3) {
                 if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
-                TailArgs t = tail_tpl;
-                t.w = tail_w; t.att1 = ATT; t.x1 = XA; t.x = XS0; t.z = nullptr; t.coef = steps_dev;
-                t.x_next = XS1; t.model_out = MOUT;
-                t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
-                ADX_HIP(tail_a(t, s));
+                ADX_TRY(launch_tail(B, XS0, nullptr, steps_dev, XS1, MOUT, s));
             } else if (stage == 4) ADX_TRY(build_chunk_cache(B, s));
             else { set_error("debug_stage: unknown stage"); return ADX_EINVAL; }
         }

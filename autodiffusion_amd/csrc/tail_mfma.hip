@@ -1,0 +1,333 @@
+// MFMA form of the fused variant-A tail (see tail_a.hip for what the tail covers): one WAVEFRONT per batch item.
+//
+// The tail is a chain of 32-wide linear maps on at most 16 rows (T+1 memory rows, T trajectory tokens) of each item.
+// Every map runs transposed on the fp32 matrix cores, Y^T = W X^T, as 16x16x4 MFMA tiles: M = 16 output features,
+// N = 16 rows (lane & 15), K = 4 input features (lane >> 4).  The accumulator of one map (lane (n, q) holds features
+// 16t + 4q + r of row n, t in {0,1}, r in 0..3) is fed back as the B operand of the next one, one register per MFMA;
+// the weight image stores A fragments with the matching permuted k order, so an activation never leaves the
+// registers between two maps.  In that layout a lane owns two complete attention heads (q and q + 4) of its row, a
+// LayerNorm is 8 registers + two cross-lane adds, and keys/values reach the other rows through a 4 KB LDS tile.
+// Weights are not staged in LDS: the image is laid out in consumption order and streamed from L2 with a two-block
+// register look-ahead (a block = one 32x32 map = 16 MFMAs), so the loads of block i+2 fly under the MFMAs of block i.
+// Arithmetic is fp32 throughout (the trajectory path stays fp32 in every precision mode).
+#include "adx_ops.h"
+#include "fastmath.h"
+
+#include <math.h>
+
+namespace adx {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int SLOT = 64;                 // float4 per slot: one per lane
+constexpr int BLOCK_SLOTS = 4;           // a 32x32 block: (mt, t) = (0,0) (0,1) (1,0) (1,1)
+constexpr int KV_LD = 68;                // LDS row stride of the key/value tile (floats)
+constexpr float LOG2E_M = 1.4426950408889634f;
+
+// ---- offsets into the vector table (floats); mirrored by tail_mfma_vec_layout below
+constexpr int V_E_BO = 0, V_E_LN2G = 32, V_E_LN2B = 64, V_E_B1 = 96, V_E_B2 = 224, V_DIN_B = 256, V_POS = 288, V_LAYER0 = 800;
+constexpr int VL_LN1G = 0, VL_LN1B = 32, VL_LN2G = 64, VL_LN2B = 96, VL_LN3G = 128, VL_LN3B = 160, VL_BQKV = 192, VL_BO = 288,
+              VL_BQ = 320, VL_BKV = 352, VL_BO2 = 416, VL_B1 = 448, VL_B2 = 576, VL_SIZE = 608;
+constexpr int V_LNFG = V_LAYER0 + 4 * VL_SIZE, V_LNFB = V_LNFG + 32, V_HEAD_B = V_LNFB + 32, V_TOTAL = V_HEAD_B + 16;
+
+struct A8 { f32x4 t[2]; };               // a [16 rows x 32 features] activation in accumulator layout
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Two-block look-ahead over the weight image.
+struct WStream {
+    const float4* p;                     // next block to fetch (already offset by the lane)
+    float4 a[BLOCK_SLOTS], b[BLOCK_SLOTS];
+    __device__ __forceinline__ void fetch(float4* dst) {
+#pragma unroll
+        for (int i = 0; i < BLOCK_SLOTS; ++i) dst[i] = p[i * SLOT];
+        p += BLOCK_SLOTS * SLOT;
+    }
+    __device__ __forceinline__ void init(const float4* first) { p = first; fetch(a); fetch(b); }
+    // hand out the oldest block, shift, and start fetching the block after next
+    __device__ __forceinline__ void pop(float4* w) {
+#pragma unroll
+        for (int i = 0; i < BLOCK_SLOTS; ++i) { w[i] = a[i]; a[i] = b[i]; }
+        fetch(b);
+    }
+};
+
+__device__ __forceinline__ f32x4 mfma4(const float4& w, const f32x4& x, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[3], acc, 0, 0, 0);
+    return acc;
+}
+
+// out = acc + W_block in   (32 inputs -> 32 outputs), next block of the stream
+__device__ __forceinline__ A8 mm32(WStream& s, const A8& in, A8 acc) {
+    float4 w[BLOCK_SLOTS];
+    s.pop(w);
+    acc.t[0] = mfma4(w[0], in.t[0], acc.t[0]);
+    acc.t[1] = mfma4(w[2], in.t[0], acc.t[1]);
+    acc.t[0] = mfma4(w[1], in.t[1], acc.t[0]);
+    acc.t[1] = mfma4(w[3], in.t[1], acc.t[1]);
+    return acc;
+}
+
+// bias of 32 features as an accumulator initial value
+__device__ __forceinline__ A8 bias8(const float* b, int q) {
+    A8 o;
+    o.t[0] = ld4(b + 4 * q);
+    o.t[1] = ld4(b + 16 + 4 * q);
+    return o;
+}
+
+__device__ __forceinline__ A8 add8(const A8& x, const A8& y) {
+    A8 o;
+    o.t[0] = x.t[0] + y.t[0];
+    o.t[1] = x.t[1] + y.t[1];
+    return o;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {      // A&S 7.1.26 erfc, |error| <= 1.5e-7
+    const float ax = fabsf(v) * 0.70710678118654752f;
+    const float t = rcp_fast(fmaf(0.3275911f, ax, 1.0f));
+    const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float hr = 0.5f * v * p * exp2_fast(-LOG2E_M * ax * ax);
+    return v > 0.f ? v - hr : hr;
+}
+
+__device__ __forceinline__ A8 gelu8(A8 x) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x.t[t][r] = gelu_erf(x.t[t][r]);
+    return x;
+}
+
+// LayerNorm over the 32 features of each row: 8 in this lane, the rest in lanes ^16, ^32, ^48
+__device__ __forceinline__ A8 ln8(const A8& y, const float* g, const float* b, int q) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += y.t[t][r];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / 32.0f);
+    A8 d;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { d.t[t][r] = y.t[t][r] - mean; v = fmaf(d.t[t][r], d.t[t][r], v); }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const float rstd = rsqrt_fast(fmaf(v, 1.0f / 32.0f, 1e-5f));
+    A8 o;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x4 ga = ld4(g + 16 * t + 4 * q), be = ld4(b + 16 * t + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.t[t][r] = fmaf(d.t[t][r] * rstd, ga[r], be[r]);
+    }
+    return o;
+}
+
+// FFN: y + W2 gelu(W1 h + b1) + b2, the hidden layer one 32-wide slice at a time (8 blocks of the stream)
+__device__ __forceinline__ A8 ffn(WStream& s, const A8& y, const A8& h, const float* b1, const float* b2, int q) {
+    A8 acc = add8(y, bias8(b2, q));
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        const A8 f = gelu8(mm32(s, h, bias8(b1 + 32 * blk, q)));
+        acc = mm32(s, f, acc);
+    }
+    return acc;
+}
+
+// keys/values of this wave's rows -> LDS tile [row][K(32) | V(32)], natural feature order
+__device__ __forceinline__ void store_kv(float* kv, const A8& k, const A8& v, int n, int q) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        *reinterpret_cast<f32x4*>(kv + n * KV_LD + 16 * t + 4 * q) = k.t[t];
+        *reinterpret_cast<f32x4*>(kv + n * KV_LD + 32 + 16 * t + 4 * q) = v.t[t];
+    }
+}
+
+// softmax attention of this lane's two heads (q and q + 4) over keys j < nk with j <= n + mask_off
+__device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int n, int q, int nk, int mask_off) {
+    const float sc = 0.5f * LOG2E_M;                    // 1 / sqrt(head_dim 4), in log2 units
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    A8 o;
+    o.t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o.t[1] = o.t[0];
+    const int last = n + mask_off;
+#pragma unroll 2
+    for (int j = 0; j < nk; ++j) {
+        const float* row = kv + j * KV_LD + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 kk = ld4(row + 16 * t), vv = ld4(row + 32 + 16 * t);
+            float s = (qv.t[t][0] * kk[0] + qv.t[t][1] * kk[1] + qv.t[t][2] * kk[2] + qv.t[t][3] * kk[3]) * sc;
+            s = j <= last ? s : -INFINITY;
+            const float mn = fmaxf(m[t], s);            // key 0 is visible to every row, so mn is finite from j = 0 on
+            const float al = exp2_fast(m[t] - mn), p = exp2_fast(s - mn);
+            l[t] = fmaf(l[t], al, p);
+            o.t[t] = o.t[t] * al + vv * p;
+            m[t] = mn;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) o.t[t] = o.t[t] * rcp_fast(l[t]);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void tail_mfma_kernel(const TailMfmaArgs a) {
+    __shared__ __attribute__((aligned(16))) float vec[V_TOTAL];
+    __shared__ __attribute__((aligned(16))) float kv_all[4][16 * KV_LD];
+    for (int i = threadIdx.x; i < V_TOTAL; i += 256) vec[i] = a.vecs[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    // every wave runs the whole body (barriers inside); waves past the batch recompute the last item and store nothing
+    const int item = blockIdx.x * 4 + wave;
+    const bool live = item < a.B;
+    const int b = min(item, a.B - 1);
+    float* kv = kv_all[wave];
+    const int T = a.T, TR = a.T + 1;
+    const float4* img = reinterpret_cast<const float4*>(a.image) + lane;
+
+    WStream ws;
+    ws.init(img + 3 * SLOT);                             // slots 0..2: input embedding and head, read directly
+    // ---- remainder of the last encoder layer on the T+1 visible rows -> memory rows XM
+    A8 att, xm;
+    {
+        const int64_t row = (int64_t)b * a.L + min(n, TR - 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            att.t[t] = ld4(a.att1 + row * 32 + 16 * t + 4 * q);
+            xm.t[t] = ld4(a.x1 + row * 32 + 16 * t + 4 * q);
+        }
+    }
+    xm = mm32(ws, att, add8(xm, bias8(vec + V_E_BO, q)));
+    xm = ffn(ws, xm, ln8(xm, vec + V_E_LN2G, vec + V_E_LN2B, q), vec + V_E_B1, vec + V_E_B2, q);
+    // ---- decoder input: input_emb(x_t) + pos_emb
+    const int nt = min(n, T - 1);
+    const float* xrow = a.x + ((int64_t)b * T + nt) * 4;
+    A8 y;
+    {
+        const float4 w = img[0];
+        const float xin = xrow[q];
+        const float* pos = vec + V_POS + nt * 32;
+        y.t[0] = ld4(vec + V_DIN_B + 4 * q) + ld4(pos + 4 * q);
+        y.t[1] = ld4(vec + V_DIN_B + 16 + 4 * q) + ld4(pos + 16 + 4 * q);
+        y.t[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, xin, y.t[0], 0, 0, 0);
+        y.t[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, xin, y.t[1], 0, 0, 0);
+    }
+#pragma unroll 1
+    for (int l = 0; l < a.n_dec; ++l) {
+        const float* lv = vec + V_LAYER0 + l * VL_SIZE;
+        // causal self-attention
+        A8 h = ln8(y, lv + VL_LN1G, lv + VL_LN1B, q);
+        const A8 qs = mm32(ws, h, bias8(lv + VL_BQKV, q));
+        const A8 ks = mm32(ws, h, bias8(lv + VL_BQKV + 32, q));
+        const A8 vs = mm32(ws, h, bias8(lv + VL_BQKV + 64, q));
+        __syncthreads();                                 // the previous readers of the tile are done
+        store_kv(kv, ks, vs, n, q);
+        __syncthreads();
+        A8 at = attend(kv, qs, n, q, T, 0);
+        y = mm32(ws, at, add8(y, bias8(lv + VL_BO, q)));
+        // cross-attention: query i sees memory rows 0..i+1
+        h = ln8(y, lv + VL_LN2G, lv + VL_LN2B, q);
+        const A8 qc = mm32(ws, h, bias8(lv + VL_BQ, q));
+        const A8 km = mm32(ws, xm, bias8(lv + VL_BKV, q));
+        const A8 vm = mm32(ws, xm, bias8(lv + VL_BKV + 32, q));
+        __syncthreads();
+        store_kv(kv, km, vm, n, q);
+        __syncthreads();
+        at = attend(kv, qc, n, q, TR, 1);
+        y = mm32(ws, at, add8(y, bias8(lv + VL_BO2, q)));
+        // feed-forward
+        y = ffn(ws, y, ln8(y, lv + VL_LN3G, lv + VL_LN3B, q), lv + VL_B1, lv + VL_B2, q);
+    }
+    // ---- ln_f, head (4 outputs: only the q == 0 lanes hold real ones), scheduler update
+    const A8 hf = ln8(y, vec + V_LNFG, vec + V_LNFB, q);
+    f32x4 out = ld4(vec + V_HEAD_B + 4 * q);
+    out = mfma4(img[1 * SLOT], hf.t[0], out);
+    out = mfma4(img[2 * SLOT], hf.t[1], out);
+    if (live && q == 0 && n < T) {
+        const StepCoef k = *a.coef;
+        const int64_t gi = ((int64_t)b * T + n) * 4;
+        const f32x4 xv = ld4(xrow);
+        f32x4 r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float x0 = fminf(fmaxf(k.a0 * xv[c] + k.a1 * out[c], -k.clip), k.clip);
+            const float eps = k.eps_mode != 0.f ? (k.b0 * xv[c] - x0) * k.b1 : out[c];
+            r[c] = k.c0 * x0 + k.c1 * xv[c] + k.c2 * eps;
+        }
+        if (k.c3 != 0.f && a.z) r = r + ld4(a.z + gi) * k.c3;
+        *reinterpret_cast<f32x4*>(a.x_next + gi) = r;
+        if (a.model_out) *reinterpret_cast<f32x4*>(a.model_out + gi) = out;
+    }
+}
+
+// One 32x32 block of W (row-major, leading dimension ldw) at (row0, col0) -> 4 slots of A fragments.
+// Rows >= n_rows and columns >= n_cols of the block are zero.
+__global__ void pack_block_kernel(const float* W, int ldw, int row0, int col0, int n_rows, int n_cols, float4* dst) {
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;      // 256 threads: slot = mt * 2 + t
+    const int mt = slot >> 1, t = slot & 1;
+    const int r = 16 * mt + (lane & 15);
+    float v[4];
+    for (int i = 0; i < 4; ++i) {
+        const int c = 16 * t + 4 * (lane >> 4) + i;
+        v[i] = (r < n_rows && c < n_cols) ? W[(int64_t)(row0 + r) * ldw + col0 + c] : 0.f;
+    }
+    dst[slot * SLOT + lane] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Slots 0..2: input embedding (K = 4: lane (m, k) holds {W[m][k], W[16 + m][k], 0, 0}) and the head (16-row tile, 2 slots).
+__global__ void pack_ends_kernel(const float* Win, const float* Whead, float4* dst) {
+    const int lane = threadIdx.x;
+    const int m = lane & 15, k = lane >> 4;
+    dst[lane] = make_float4(Win[m * 4 + k], Win[(16 + m) * 4 + k], 0.f, 0.f);
+    for (int t = 0; t < 2; ++t) {
+        float v[4];
+        for (int i = 0; i < 4; ++i) v[i] = m < 4 ? Whead[m * 32 + 16 * t + 4 * k + i] : 0.f;
+        dst[(1 + t) * SLOT + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+}  // namespace
+
+int tail_mfma_vec_floats() { return V_TOTAL; }
+int tail_mfma_blocks(int n_dec) { return 9 + 16 * n_dec; }
+size_t tail_mfma_image_bytes(int n_dec) {
+    return sizeof(float4) * SLOT * (3 + (size_t)BLOCK_SLOTS * (tail_mfma_blocks(n_dec) + 2));    // + look-ahead padding
+}
+
+TailMfmaVecLayout tail_mfma_vec_layout() {
+    TailMfmaVecLayout v;
+    v.e_bo = V_E_BO; v.e_ln2_g = V_E_LN2G; v.e_ln2_b = V_E_LN2B; v.e_b1 = V_E_B1; v.e_b2 = V_E_B2;
+    v.din_b = V_DIN_B; v.pos = V_POS; v.layer0 = V_LAYER0; v.layer_size = VL_SIZE;
+    v.ln1_g = VL_LN1G; v.ln1_b = VL_LN1B; v.ln2_g = VL_LN2G; v.ln2_b = VL_LN2B; v.ln3_g = VL_LN3G; v.ln3_b = VL_LN3B;
+    v.bqkv = VL_BQKV; v.bo = VL_BO; v.bq = VL_BQ; v.bkv = VL_BKV; v.bo2 = VL_BO2; v.b1 = VL_B1; v.b2 = VL_B2;
+    v.lnf_g = V_LNFG; v.lnf_b = V_LNFB; v.head_b = V_HEAD_B;
+    return v;
+}
+
+hipError_t tail_mfma_pack_block(const float* W, int ldw, int row0, int col0, void* image, int block, hipStream_t stream) {
+    float4* dst = reinterpret_cast<float4*>(image) + (size_t)SLOT * (3 + (size_t)BLOCK_SLOTS * block);
+    hipLaunchKernelGGL(pack_block_kernel, dim3(1), dim3(256), 0, stream, W, ldw, row0, col0, 32, 32, dst);
+    return hipGetLastError();
+}
+
+hipError_t tail_mfma_pack_ends(const float* Win, const float* Whead, void* image, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_ends_kernel, dim3(1), dim3(64), 0, stream, Win, Whead, reinterpret_cast<float4*>(image));
+    return hipGetLastError();
+}
+
+hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.T <= 0 || a.T + 1 > 16 || a.n_dec < 0 || a.n_dec > 4 || !a.image || !a.vecs) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tail_mfma_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace adx
