@@ -81,6 +81,17 @@ hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream);
 // Q/O/state address rows exactly as in AttentionArgs (Sq rows per batch item).  head_dim 4.
 hipError_t attention_merge_key(const AttentionArgs& a, hipStream_t stream);
 
+// Attention of query rows that every batch item shares (the time token under each scheduler step: row s of `table`
+// holds its q | k | v, 32 floats each) over Skv keys of the item plus the row's own key.  O is [NS][B][32].  8 heads x 4.
+struct TimeRowsArgs {
+    const float* table = nullptr; int64_t ldt = 0;
+    const float* K = nullptr; const float* V = nullptr; int64_t ldk = 0, k_batch_stride = 0;
+    float* O = nullptr;
+    int B = 0, NS = 0, Skv = 0;
+    float scale = 1.f;
+};
+hipError_t attention_time_rows(const TimeRowsArgs& a, hipStream_t stream);
+
 // Fused per-row pipeline of the variant-A encoder (d_model 32, 8 heads, FFN 128); see fused_a.hip.
 // For every conditioning row: fold the time-token key (key0 = [k(32), v(32)]) into the cached layer-0 softmax state
 // (row 0 of each item takes its attention output from att0 instead), out_proj + residual, LayerNorm, FFN + residual,
@@ -91,7 +102,8 @@ struct EncRowsArgs {
     const float* q = nullptr; int64_t ldq = 0;       // layer-0 queries, row stride ldq           } read by enc_rows_pack,
     const float* state = nullptr;                    // [B*L][8][6] {m, l, o[4]}                  } not by enc_rows
     const float4* packed = nullptr;                  // x0, q, state of every row in lane order (enc_rows_packed_bytes)
-    const float* att0 = nullptr;                     // [B*L][32], only row 0 of each item is read
+    const float* att0 = nullptr;                     // [B][32] layer-0 attention output of row 0 (the time token) of each item
+    const float* x0_time = nullptr;                  // [32] encoder input of row 0, the same for every item
     const float* key0 = nullptr;                     // [64]
     const void* image = nullptr;                     // weight fragment image from enc_rows_build_image
     const float* img_f32 = nullptr; const unsigned short* img_bf = nullptr;   // filled by the launcher

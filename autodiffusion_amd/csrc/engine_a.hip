@@ -45,6 +45,8 @@ struct EngineA final : adx_engine {
     // (rows >= 1 do not depend on the diffusion step); ST: softmax state of every query row >= 1 over key rows >= 1;
     // tqkv0: per-step q/k/v of the time token (identical for every batch item), [n_steps][3d].
     float *QKV0 = nullptr, *ST = nullptr, *PK = nullptr, *tqkv0 = nullptr;
+    // fused path: tx0[s] = encoder input of the time token at step s; ATT0[s][b] = its layer-0 attention output
+    float *tx0 = nullptr, *ATT0 = nullptr;
     bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
     // elide level 3: the per-row pipeline between the two encoder attentions runs as one fused kernel
     bool fused = false;
@@ -63,6 +65,7 @@ struct EngineA final : adx_engine {
         if (rows_image) (void)hipFree(rows_image);
         if (rows_vecs) (void)hipFree(rows_vecs);
         if (tail_w) (void)hipFree(tail_w);
+        if (tx0) (void)hipFree(tx0);
         if (tailm_image) (void)hipFree(tailm_image);
         if (tailm_vecs) (void)hipFree(tailm_vecs);
     }
@@ -128,7 +131,10 @@ struct EngineA final : adx_engine {
         take(&TRAW, (size_t)B * NP * Cp); take(&PRAW, (size_t)B * NP * Cp); take(&CHO, BT * Cin);
         take(&TE, (size_t)B * d);
         if (cfg.elide >= 2) { take(&QKV0, BL * 3 * d); take(&ST, BL * H * 6); }
-        if (fused) take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
+        if (fused) {
+            take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
+            take(&ATT0, (size_t)B * std::max<size_t>(steps.size(), 1) * d);
+        }
         *bytes = off;
         return ADX_OK;
     }
@@ -140,13 +146,16 @@ struct EngineA final : adx_engine {
             // q/k/v of the time token under encoder layer 0, one row per step
             if (tqkv0) (void)hipFree(tqkv0);
             tqkv0 = nullptr;
+            if (tx0) (void)hipFree(tx0);
+            tx0 = nullptr;
             float* tmp = nullptr;
             ADX_HIP(hipMalloc(&tqkv0, sizeof(float) * (size_t)n * 3 * d));
+            ADX_HIP(hipMalloc(&tx0, sizeof(float) * (size_t)n * d));
             ADX_HIP(hipMalloc(&tmp, sizeof(float) * (size_t)n * d));
             const std::string p = "encoder.layers.0";
-            hipError_t e = add_vec_act(temb_table, P("cond_pos_emb"), tmp, n, d, 0, ACT_NONE, s);
+            hipError_t e = add_vec_act(temb_table, P("cond_pos_emb"), tx0, n, d, 0, ACT_NONE, s);
             int rc = ADX_OK;
-            if (e == hipSuccess) rc = ln_rows(tmp, tmp, p + ".norm1", n, RowMap{}, s);
+            if (e == hipSuccess) rc = ln_rows(tx0, tmp, p + ".norm1", n, RowMap{}, s);
             if (e == hipSuccess && rc == ADX_OK)
                 e = linear(lin(tmp, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", tqkv0, 3 * d, n), s);
             (void)hipStreamSynchronize(s);
@@ -314,14 +323,24 @@ struct EngineA final : adx_engine {
         at.B = B; at.H = H; at.Sq = L - 1; at.Skv = L - 1; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
         at.state = ST + H * 6; at.state_ld = H * 6; at.state_batch_stride = (int64_t)L * H * 6;
         ADX_HIP(attention(at, s));
-        if (fused) ADX_HIP(enc_rows_pack(rows_args(B, nullptr), s));
+        if (fused) {
+            ADX_HIP(enc_rows_pack(rows_args(B, 0), s));
+            // the time token's attention for every step of the chunk in one pass over the keys
+            TimeRowsArgs tr;
+            tr.table = tqkv0; tr.ldt = 3 * d;
+            tr.K = QKV0 + 3 * d + d; tr.V = QKV0 + 3 * d + 2 * d; tr.ldk = 3 * d; tr.k_batch_stride = (int64_t)L * 3 * d;
+            tr.O = ATT0; tr.B = B; tr.NS = (int)steps.size(); tr.Skv = L - 1; tr.scale = at.scale;
+            ADX_HIP(attention_time_rows(tr, s));
+        }
         return ADX_OK;
     }
 
-    EncRowsArgs rows_args(int B, const float* tq) const {
+    EncRowsArgs rows_args(int B, int step) const {
         EncRowsArgs r;
         r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.packed = reinterpret_cast<const float4*>(PK);
-        r.att0 = ATT; r.key0 = tq ? tq + d : nullptr;
+        r.att0 = ATT0 + (int64_t)step * B * d;     // [step][B][d] for the batch of this call
+        r.x0_time = tx0 + (int64_t)step * d;
+        r.key0 = tqkv0 + (int64_t)step * 3 * d + d;
         r.image = rows_image; r.vecs = rows_vecs;
         r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
@@ -400,9 +419,7 @@ struct EngineA final : adx_engine {
         bool last_attn_done = false;      // ATT already holds the last encoder layer's attention for rows 0..T
         if (step >= 0 && fused) {
             // layer 0 and layer 1 up to its attention: three launches
-            ADX_TRY(time_token_attention(B, step, s));
-            const float* tq = tqkv0 + (int64_t)step * 3 * d;
-            ADX_HIP(enc_rows(rows_args(B, tq), cfg.precision, s));
+            ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s));
             ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
             if (tail_ok && io.x_next && stepped) {
                 ADX_TRY(launch_tail(B, x, io.z, steps_dev + step, io.x_next, out, s));
@@ -511,11 +528,10 @@ struct EngineA final : adx_engine {
     // 3 fused tail, 4 per-chunk cache build.  Needs a previous generate/sample call with the same B.
     int debug_stage(int B, int stage, int iters, hipStream_t s) {
         if (!finalized || steps.empty() || B > max_batch || !fused) { set_error("debug_stage: engine not ready (needs elide 3, a schedule and a prior call)"); return ADX_ESTATE; }
-        const float* tq = tqkv0;
         for (int it = 0; it < iters; ++it) {
             if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
             else if (stage == 1) {
-                ADX_HIP(enc_rows(rows_args(B, tq), cfg.precision, s));
+                ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s));
             } else if (stage == 2) ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
             else if (stage == 3) {
                 if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
@@ -565,7 +581,7 @@ struct EngineA final : adx_engine {
         if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, s));
         else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, s));
         for (size_t k = 0; k < steps.size(); ++k) {
-            ADX_TRY(set_time(B, temb_table + k * d, 0, s));
+            if (!fused) ADX_TRY(set_time(B, temb_table + k * d, 0, s));   // the fused path reads the time token from tables
             const int zi = (int)steps[k].z_index;
             const float* z = nullptr;
             if (zi >= 0 && steps[k].c3 != 0.f) {

@@ -165,6 +165,11 @@ int adx_engine::set_schedule(const adx_step_coef* s, int n) {
     ++schedule_version;
     ADX_TRY(build_time_table(nullptr));
     ADX_HIP(hipStreamSynchronize(nullptr));
+    if (ws) {                                   // per-step buffers in the workspace scale with the schedule length
+        const int mb = max_batch;
+        max_batch = 0;
+        ADX_TRY(reserve(mb));
+    }
     return ADX_OK;
 }
 

@@ -225,14 +225,13 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
         load_row(in, a.packed + (tile0 >> 5) * (PACK_VECS * 64) + lane);
         // ---- attention output of layer 0 in accumulator layout: register 4g+i <-> feature 8g + 4h + i
         f32x16 att;
-        if (r == 0) {                                           // the time token changes every step: read it in place
-            const float* ap = a.att0 + row * D;
-            const float* xp = a.x0 + row * D;
+        if (r == 0) {                                           // the time token: inputs change every step
+            const float* ap = a.att0 + (int64_t)((unsigned)row / (unsigned)a.L) * D;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t = *reinterpret_cast<const float4*>(ap + 8 * g + 4 * h);
                 att[4 * g] = t.x; att[4 * g + 1] = t.y; att[4 * g + 2] = t.z; att[4 * g + 3] = t.w;
-                in.x[g] = *reinterpret_cast<const float4*>(xp + 8 * g + 4 * h);
+                in.x[g] = *reinterpret_cast<const float4*>(a.x0_time + 8 * g + 4 * h);
             }
         } else {
             const float* stf = reinterpret_cast<const float*>(in.st);
@@ -338,7 +337,7 @@ hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream) {
 }
 
 hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
-    if (a0.B <= 0 || a0.L <= 0 || !a0.image || !a0.packed || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
+    if (a0.B <= 0 || a0.L <= 0 || !a0.image || !a0.packed || !a0.att0 || !a0.x0_time || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
     EncRowsArgs a = a0;
     a.img_f32 = reinterpret_cast<const float*>(a.image);
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);

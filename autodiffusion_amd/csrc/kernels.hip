@@ -550,6 +550,55 @@ hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Shared query rows (see TimeRowsArgs): a thread owns (head, query); a workgroup covers 32 queries of one item and
+// walks the item's keys through a 64-row LDS tile that all 32 queries reuse.
+__global__ __launch_bounds__(256) void attn_time_rows_kernel(const TimeRowsArgs a) {
+    constexpr int KT = 64;
+    __shared__ __attribute__((aligned(16))) float4 KVs[KT][16];      // row: k (8 float4), v (8 float4)
+    const int b = blockIdx.y, tid = threadIdx.x, h = tid & 7;
+    const int s = min((int)blockIdx.x * 32 + (tid >> 3), a.NS - 1);
+    const float* row = a.table + (int64_t)s * a.ldt;
+    const float f = a.scale * LOG2E;
+    float4 q = *reinterpret_cast<const float4*>(row + 4 * h);
+    q.x *= f; q.y *= f; q.z *= f; q.w *= f;
+    // the row's own key opens the running softmax
+    const float4 k0 = *reinterpret_cast<const float4*>(row + 32 + 4 * h);
+    float4 o = *reinterpret_cast<const float4*>(row + 64 + 4 * h);
+    float m = fmaf(q.x, k0.x, fmaf(q.y, k0.y, fmaf(q.z, k0.z, q.w * k0.w))), l = 1.f;
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride;
+    const float* Vb = a.V + (int64_t)b * a.k_batch_stride;
+    for (int j0 = 0; j0 < a.Skv; j0 += KT) {
+        const int nk = min(KT, a.Skv - j0);
+        __syncthreads();
+        for (int i = tid; i < KT * 16; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            if (r < nk) KVs[r][c] = *reinterpret_cast<const float4*>((c < 8 ? Kb : Vb) + (int64_t)(j0 + r) * a.ldk + 4 * (c & 7));
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < nk; ++j) {
+            const float4 kk = KVs[j][h], vv = KVs[j][8 + h];
+            const float sc = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+            const float mn = fmaxf(m, sc);
+            const float al = exp2_fast(m - mn), p = exp2_fast(sc - mn);
+            l = fmaf(l, al, p);
+            o.x = fmaf(o.x, al, p * vv.x); o.y = fmaf(o.y, al, p * vv.y);
+            o.z = fmaf(o.z, al, p * vv.z); o.w = fmaf(o.w, al, p * vv.w);
+            m = mn;
+        }
+    }
+    if ((int)blockIdx.x * 32 + (tid >> 3) < a.NS) {
+        const float inv = rcp_fast(l);
+        *reinterpret_cast<float4*>(a.O + ((int64_t)s * a.B + b) * 32 + 4 * h) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+    }
+}
+
+hipError_t attention_time_rows(const TimeRowsArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.NS <= 0 || a.Skv < 0 || !a.table || !a.K || !a.V || !a.O) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_time_rows_kernel, dim3((a.NS + 31) / 32, a.B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 // One thread per (row, head); heads fastest so that a wave touches whole rows of Q, state and O.
 __global__ __launch_bounds__(256) void attn_merge_key_kernel(const AttentionArgs a) {
     constexpr int DH = 4;

@@ -78,8 +78,8 @@ def roofline(da, B):
     at the dense bf16 MFMA peak).  ``stages_us`` lists the other kernels of a call, timed the same way.
     """
     eng = da.diffusion.diffusion.model.engine()
-    names = ["time_token_attention", "enc_rows", "last_layer_attention", "tail", "chunk_cache_build"]
-    t = {n: time_kernel(lambda k, i=i: eng.debug_stage_a(B, i, k), 4 if n == "chunk_cache_build" else 20) for i, n in enumerate(names)}
+    names = {1: "enc_rows", 2: "last_layer_attention", 3: "tail", 4: "chunk_cache_build"}
+    t = {n: time_kernel(lambda k, i=i: eng.debug_stage_a(B, i, k), 4 if i == 4 else 20) for i, n in names.items()}
     rows = B * L_COND
     algo = float(ENC_ROWS_ALGO_BYTES_PER_ROW * rows)
     achieved = algo / t["enc_rows"] / 1e9

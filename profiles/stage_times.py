@@ -17,8 +17,8 @@ out = torch.empty(B, 80, 4, device=dev)
 da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
 torch.cuda.synchronize()
 eng = da.diffusion.diffusion.model.engine()
-names = ["time-token attention", "fused encoder rows", "last-layer attention", "fused tail", "chunk cache build"]
-for stage, name in enumerate(names):
+names = {1: "fused encoder rows", 2: "last-layer attention", 3: "fused tail", 4: "chunk cache build"}
+for stage, name in names.items():
     iters = 3 if stage == 4 else 20
     eng.debug_stage_a(B, stage, 2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
