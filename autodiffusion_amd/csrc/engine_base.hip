@@ -189,8 +189,10 @@ ADX_API int adx_op_timestep_embedding(const int64_t* t, int n, int dim, float* o
 ADX_API int adx_op_linear(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
                           int prec, void* stream) {
     if (!x || !w || !y) return fail(ADX_EINVAL, "linear: null pointer");
-    if (prec != ADX_PREC_F32 && prec != ADX_PREC_BF16) return fail(ADX_EINVAL, "linear: precision must be ADX_PREC_F32 or ADX_PREC_BF16");
+    if (prec != ADX_PREC_F32 && prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "linear: unknown precision");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(ADX_EINVAL, "linear: empty shape");
     LinearArgs a;
+    if (prec == ADX_PREC_BF16X3) a.Wlo = reinterpret_cast<const uint16_t*>(w) + (int64_t)N * K;
     a.X = x; a.ldx = K; a.W = w; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
     return done(linear(a, (hipStream_t)stream), "linear");
 }

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
     const int64_t n_rows = (int64_t)a.B * a.L;
 
     for (int64_t tile0 = (int64_t)wave_global * 32; tile0 < n_rows; tile0 += (int64_t)n_waves * 32) {
+        asm volatile("" ::: "memory");      // keep the per-lane bias / LayerNorm vectors in LDS: hoisting them costs ~100 registers
         const int64_t row = min(tile0 + c, n_rows - 1);          // clamp: out-of-range lanes recompute the last row, never store
         const bool live = tile0 + c < n_rows;
         const int r = (int)((unsigned)row % (unsigned)a.L);      // B * L < 2^31 is checked by the launcher
@@ -343,7 +344,7 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
     const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 64) * 4;
     const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32;
-    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 2; }();   // tuning knob: 3 waves per SIMD spills, and the spills reach HBM
+    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 3; }();   // tuning knob (2 or 3 resident waves per SIMD)
     int blocks = (int)((tiles + 3) / 4);
     const int cap = 256 * (waves == 3 ? 3 : 2);        // resident workgroups; waves stride over the remaining tiles
     if (blocks > cap) blocks = cap;

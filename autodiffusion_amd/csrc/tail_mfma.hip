@@ -7,8 +7,8 @@
 // the weight image stores A fragments with the matching permuted k order, so an activation never leaves the
 // registers between two maps.  In that layout a lane owns two complete attention heads (q and q + 4) of its row, a
 // LayerNorm is 8 registers + two cross-lane adds, and keys/values reach the other rows through a 4 KB LDS tile.
-// Weights are not staged in LDS: the image is laid out in consumption order and streamed from L2 with a two-block
-// register look-ahead (a block = one 32x32 map = 16 MFMAs), so the loads of block i+2 fly under the MFMAs of block i.
+// Weights are not staged in LDS: the image is laid out in consumption order and streamed from L2 with a four-block
+// register look-ahead (a block = one 32x32 map = 16 MFMAs), so the loads of block i+4 fly under the MFMAs of block i.
 // Arithmetic is fp32 throughout (the trajectory path stays fp32 in every precision mode).
 #include "adx_ops.h"
 #include "fastmath.h"
@@ -35,21 +35,30 @@ struct A8 { f32x4 t[2]; };               // a [16 rows x 32 features] activation
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// Two-block look-ahead over the weight image.
+// DEPTH-block look-ahead over the weight image (registers; the shifts are moves that issue under the MFMAs).
+constexpr int DEPTH = 4;
 struct WStream {
     const float4* p;                     // next block to fetch (already offset by the lane)
-    float4 a[BLOCK_SLOTS], b[BLOCK_SLOTS];
+    float4 a[DEPTH][BLOCK_SLOTS];
     __device__ __forceinline__ void fetch(float4* dst) {
 #pragma unroll
         for (int i = 0; i < BLOCK_SLOTS; ++i) dst[i] = p[i * SLOT];
         p += BLOCK_SLOTS * SLOT;
     }
-    __device__ __forceinline__ void init(const float4* first) { p = first; fetch(a); fetch(b); }
-    // hand out the oldest block, shift, and start fetching the block after next
+    __device__ __forceinline__ void init(const float4* first) {
+        p = first;
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) fetch(a[k]);
+    }
+    // hand out the oldest block, shift, and start fetching the block DEPTH ahead
     __device__ __forceinline__ void pop(float4* w) {
 #pragma unroll
-        for (int i = 0; i < BLOCK_SLOTS; ++i) { w[i] = a[i]; a[i] = b[i]; }
-        fetch(b);
+        for (int i = 0; i < BLOCK_SLOTS; ++i) w[i] = a[0][i];
+#pragma unroll
+        for (int k = 0; k + 1 < DEPTH; ++k)
+#pragma unroll
+            for (int i = 0; i < BLOCK_SLOTS; ++i) a[k][i] = a[k + 1][i];
+        fetch(a[DEPTH - 1]);
     }
 };
 
@@ -300,7 +309,7 @@ __global__ void pack_ends_kernel(const float* Win, const float* Whead, float4* d
 int tail_mfma_vec_floats() { return V_TOTAL; }
 int tail_mfma_blocks(int n_dec) { return 9 + 16 * n_dec; }
 size_t tail_mfma_image_bytes(int n_dec) {
-    return sizeof(float4) * SLOT * (3 + (size_t)BLOCK_SLOTS * (tail_mfma_blocks(n_dec) + 2));    // + look-ahead padding
+    return sizeof(float4) * SLOT * (3 + (size_t)BLOCK_SLOTS * (tail_mfma_blocks(n_dec) + DEPTH));    // + look-ahead padding
 }
 
 TailMfmaVecLayout tail_mfma_vec_layout() {

@@ -26,15 +26,28 @@ def to_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def prepare_weight(w: torch.Tensor, precision: str = "fp32") -> torch.Tensor:
+    """The device form of an (N, K) weight that ``adx_op_linear`` reads under ``precision``."""
+    prec = _lib.PRECISIONS[precision]
+    if prec == _lib.PREC_BF16:
+        return to_bf16(w)
+    if prec == _lib.PREC_BF16X3:
+        hi = to_bf16(w)
+        hi_f = (hi.to(torch.int32) << 16).view(torch.float32)
+        return torch.cat([hi.reshape(-1), to_bf16(f32c(w) - hi_f).reshape(-1)])
+    return f32c(w)
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = _lib.ACT_NONE,
-           precision: str = "fp32") -> torch.Tensor:
+           precision: str = "fp32", prepared_n: int = 0) -> torch.Tensor:
+    """``act(x w^T + bias)``.  With ``prepared_n`` > 0, ``w`` is already the result of ``prepare_weight`` for N = prepared_n."""
     lib = _lib.load()
     x = f32c(x)
     K = x.shape[-1]
-    N = w.shape[0]
+    N = prepared_n or w.shape[0]
     M = x.numel() // K
-    prec = {"fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}[precision]
-    wd = to_bf16(w) if prec == _lib.PREC_BF16 else f32c(w)
+    prec = _lib.PRECISIONS[precision]
+    wd = w if prepared_n else prepare_weight(w, precision)
     b = f32c(bias) if bias is not None else None
     y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
     check(lib.adx_op_linear(ptr(x), ptr(wd), ptr(b), ptr(y), M, N, K, act, prec, current_stream()), "linear")

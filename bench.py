@@ -6,7 +6,7 @@
 Workload (BASELINE.json configs[1]): the strDiffDiT-style refiner -- encoder/decoder Transformer denoiser,
 d=32, 8 heads, 2 encoder + 4 decoder layers, frame_stack 10 (8 chunks of 10 trajectory tokens, 809
 conditioning tokens), in-repo DDIM sampler 50 of 100 steps (eta 0, cosine schedule, pred_noise), bf16 MFMA GEMMs
-(split operands by default, see --precision) / fp32 state, B = 1024 scenarios per GPU, random-init weights, synthetic nuPlan-shaped conditioning
+(split operands by default, see --precision) / fp32 state, B = 4096 scenarios per GPU, random-init weights, synthetic nuPlan-shaped conditioning
 already resident in HBM.  One "step" = one generate() pass over the batch: 8 chunks x 50 denoiser calls +
 scheduler updates, replayed from one hipGraph, plus (N > 1) the all-gather of the sampled trajectories.
 
@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 FS, N_TRAIN, N_SAMPLE, L_COND, D_MODEL, N_HEAD = 10, 100, 50, 809, 32, 8
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 
 def build_model(dev, precision="bf16"):
@@ -89,6 +90,67 @@ def roofline(da, B):
             "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()}}
 
 
+# ------------------------------------------------------------------------------------------------ DiT decoder workloads
+DIT_WORKLOADS = {           # name: (backbone, d, layers, heads, diffusion steps, default batch)
+    "dit256": ("DiT", 256, 4, 8, 10, 4096),
+    "mmdit256": ("MM-DiT", 256, 4, 8, 10, 2048),
+    "dit1024": ("DiT", 1024, 24, 16, 200, 256),
+}
+
+
+def dit_macs_per_step(d, L, S=80):
+    """Dense multiply-accumulates of one DiT denoiser call on one trajectory (state encoder excluded: once per scenario)."""
+    x_enc = 1942272 + 768 * 2048 + 2816 * d
+    return L * (26 * S * d * d + 2 * S * S * d) + S * x_enc + (2 * S * d * d + 4 * S * d) + 8 * d * d
+
+
+def bench_dit(args, dev):
+    """DiffusionDecoder.generate with stochastic sampling (determin=False): B trajectories x N DDPM steps per pass."""
+    from autodiffusion_amd import dit, ops, synth
+    backbone, d, L, h, n_steps, b_def = DIT_WORKLOADS[args.workload]
+    B = args.batch or b_def
+    cfg = dit.dit_config(d, L, h, backbone, k=1, mc_num=1, diffusion_timesteps=n_steps, precision=args.precision)
+    dec = dit.DiffusionDecoder(cfg).to(dev).eval()
+    torch.manual_seed(11)
+    with torch.no_grad():
+        for p in dec.parameters():          # every tensor N(0, 0.02): the reference zero-inits adaLN, which would idle the blocks
+            p.normal_(0.0, 0.02)
+    state = synth.hidden_state(B, cfg.n_embd, 7).to(dev)
+    noise = synth.noise(B, (n_steps + 1,), (80, 4), 1234).to(dev)
+
+    def step():
+        return dec.model(state, batch_size=B, determin=False, noise=noise)
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    assert bool(torch.isfinite(out).all())
+    # dominant GEMM: the 4d-wide MLP / FFN expansions, M = B * 80 tokens
+    M, N, K = B * 80, 4 * d, d
+    x = torch.randn(M, K, device=dev)
+    w = ops.prepare_weight(torch.randn(N, K, device=dev) * 0.02, args.precision)
+    bias = torch.zeros(N, device=dev)
+    tg = time_kernel(lambda k: [ops.linear(x, w, bias, precision=args.precision, prepared_n=N) for _ in range(k)], 10)
+    achieved = 2.0 * M * N * K / tg / 1e12
+    flops = 2.0 * dit_macs_per_step(d, L) * B * n_steps
+    line = {
+        "metric": "denoised trajectories/sec (8s, 80-pt)", "value": round(B / dt, 2), "unit": "trajectories/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": f"{backbone} decoder d={d} L={L} h={h}, {n_steps} DDPM steps (cosine), stochastic sampling, random init, "
+                               "synthetic backbone hidden states", "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
+                   "precision": args.precision, "dense_tflops_whole_pass": round(flops / dt / 1e12, 2)},
+        "roofline": {"kernel": f"linear_kernel M={M} N={N} K={K}", "bound": "mfma", "achieved": round(achieved, 2),
+                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                     "traffic": None, "launch_us": round(tg * 1e6, 1)},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def cpu_baseline():
     """The fp32 CPU oracle on one chunk (of 8) of a 16-scenario batch, all 50 DDIM steps."""
     from autodiffusion_amd import synth
@@ -121,7 +183,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="scenarios per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 4096 for the refiner)")
+    ap.add_argument("--workload", default="refiner", choices=["refiner"] + sorted(DIT_WORKLOADS),
+                    help="refiner = the headline configuration; the DiT decoder workloads run on one GPU only")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -137,8 +201,13 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload != "refiner":
+        if world > 1:
+            raise SystemExit("the DiT workloads are single-GPU measurements")
+        return bench_dit(args, dev)
+
     from autodiffusion_amd.distributed import all_gather_rows
-    B = args.batch
+    B = args.batch or 4096
     da = build_model(dev, args.precision)
     maps, prior, noise = make_inputs(B, rank * B, dev)
     out = torch.empty(B, 80, 4, device=dev)

@@ -54,7 +54,8 @@ int adx_op_timestep_embedding(const int64_t* t, int n, int dim, float* out, void
 
 /* torch.nn.Linear (+ fused activation): y[M][N] = act(x[M][K] w[N][K]^T + bias).  With
  * ADX_PREC_BF16, `w` holds bf16 bit patterns (see adx_op_to_bf16) and x is rounded to bf16 as it
- * is staged.  Stands in for every nn.Linear on the path (transformer.py:50,60-61,133;
+ * is staged; with ADX_PREC_BF16X3, `w` holds N*K high parts followed by N*K low parts
+ * (bf16(w) and bf16(w - bf16(w))) and x is split the same way on the fly.  Stands in for every nn.Linear on the path (transformer.py:50,60-61,133;
  * libs/diffusionTransformer.py:38-47,63-76,134-165,189-193; libs/mlp.py:28,50). */
 int adx_op_linear(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
                   int prec, void* stream);

@@ -28,3 +28,20 @@ for stage, name in names.items():
     e.record()
     torch.cuda.synchronize()
     print(f"{prec} B={B} stage {stage} {name:22s} {s.elapsed_time(e) / iters * 1e3:9.1f} us")
+
+# the tail right after the streaming kernels (its weight image no longer in L2), as inside a sampling step
+def pair(stages, iters=20):
+    for st in stages:
+        eng.debug_stage_a(B, st, 1)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        for st in stages:
+            eng.debug_stage_a(B, st, 1)
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+print(f"{prec} B={B} stages 1+2       {pair([1, 2]):9.1f} us")
+print(f"{prec} B={B} stages 1+2+3     {pair([1, 2, 3]):9.1f} us")
