@@ -36,7 +36,9 @@ struct LinearArgs {
     int col_group = 0, col_stride = 0, col_off = 0;
     int prec = PREC_F32;
 };
-hipError_t linear(const LinearArgs& a, hipStream_t stream);
+hipError_t linear(const LinearArgs& a, hipStream_t stream);        // picks linear_big when linear_big_ok(a)
+bool linear_big_ok(const LinearArgs& a);                             // large-tile bf16 kernel (gemm.hip) applies
+hipError_t linear_big(const LinearArgs& a, hipStream_t stream);
 
 // y = LN(x) [* gamma + beta] [* (1 + scale) + shift] [relu]; rows of length d.
 struct LayerNormArgs {

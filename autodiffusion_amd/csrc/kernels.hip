@@ -4,6 +4,7 @@
 #include "fastmath.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace adx {
 
@@ -256,6 +257,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
 
 hipError_t linear(const LinearArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+    static const bool small_only = [] { const char* e = getenv("ADX_LINEAR_SMALL"); return e && e[0] == '1'; }();   // tuning knob
+    if (!small_only && linear_big_ok(a)) return linear_big(a, stream);
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
     if (a.prec == PREC_BF16X3) {
         if (!a.Wlo) return hipErrorInvalidValue;

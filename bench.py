@@ -108,6 +108,7 @@ def bench_dit(args, dev):
     """DiffusionDecoder.generate with stochastic sampling (determin=False): B trajectories x N DDPM steps per pass."""
     from autodiffusion_amd import dit, ops, synth
     backbone, d, L, h, n_steps, b_def = DIT_WORKLOADS[args.workload]
+    n_steps = args.dit_steps or n_steps
     B = args.batch or b_def
     cfg = dit.dit_config(d, L, h, backbone, k=1, mc_num=1, diffusion_timesteps=n_steps, precision=args.precision)
     dec = dit.DiffusionDecoder(cfg).to(dev).eval()
@@ -186,6 +187,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 4096 for the refiner)")
     ap.add_argument("--workload", default="refiner", choices=["refiner"] + sorted(DIT_WORKLOADS),
                     help="refiner = the headline configuration; the DiT decoder workloads run on one GPU only")
+    ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -57,6 +57,32 @@ def test_op_linear(dev, M, N, K, prec):
             assert rel_err(y, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 64, 32), (300, 200, 96), (1000, 130, 2816), (5120, 1024, 256), (641, 384, 1536), (40001, 1700, 64),
+                                   (33000, 520, 192)])
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_op_linear_large_tile(dev, M, N, K, prec):
+    """Shapes that take the 128x128-tile kernel (M >= 256, K % 32 == 0), ragged M and N included."""
+    from autodiffusion_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    for act, fn in ((_lib.ACT_NONE, lambda v: v), (_lib.ACT_GELU_TANH, lambda v: torch.nn.functional.gelu(v, approximate="tanh"))):
+        y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act, prec).cpu()
+        if prec == "bf16":
+            ref = fn(x.bfloat16().double() @ w.bfloat16().double().T + b.double()).float()
+            assert rel_err(y, ref) < 2e-5
+        else:
+            ref = fn(x.double() @ w.double().T + b.double()).float()
+            assert rel_err(y, ref) < 2e-5     # split operands: ~16 mantissa bits per factor
+    # asymmetric integer weights against a permutation-like X: catches a transposed or mis-swizzled tile
+    n = 256
+    xi = torch.eye(n)[torch.randperm(n, generator=g)]
+    wi = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) - 100.0
+    yi = ops.linear(xi.to(dev), wi.to(dev), None, precision=prec).cpu()
+    assert torch.equal(yi, xi @ wi.T)
+
+
 def test_op_linear_asymmetric_identity(dev):
     """A = I against an asymmetric W catches a transposed accumulator layout."""
     from autodiffusion_amd import ops
