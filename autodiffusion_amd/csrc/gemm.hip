@@ -83,9 +83,9 @@ __device__ __forceinline__ void fetch(Stage<X3, WM>& s, const StagePlan<X3, WM>&
     }
 }
 
-template <bool X3>
-__device__ __forceinline__ void stash_x(float4 v, int r, int xk, int in_act, unsigned char* Ah, unsigned char* Al) {
-    if (in_act == ACT_SILU) {                     // the only input activation on the path (adaLN modulation)
+template <bool X3, bool SILU>
+__device__ __forceinline__ void stash_x(float4 v, int r, int xk, unsigned char* Ah, unsigned char* Al) {
+    if constexpr (SILU) {                         // the only input activation on the path (adaLN modulation)
         v.x = act_fn(v.x, ACT_SILU); v.y = act_fn(v.y, ACT_SILU); v.z = act_fn(v.z, ACT_SILU); v.w = act_fn(v.w, ACT_SILU);
     }
     const int o = swz(r, xk >> 3) + ((xk & 4) << 1);
@@ -103,17 +103,17 @@ __device__ __forceinline__ void stash_x(float4 v, int r, int xk, int in_act, uns
 // stage layout: [A_hi (64 WM rows)] [B_hi (128 rows)] [A_lo] [B_lo]
 template <int WM> __device__ __forceinline__ constexpr int atile_b() { return 64 * WM * ROW_B; }
 
-template <bool X3, int WM>
+template <bool X3, int WM, bool SILU>
 __device__ __forceinline__ void stash(const Stage<X3, WM>& s, const StagePlan<X3, WM>& p, unsigned char* st) {
     unsigned char* Ah = st;
     unsigned char* Bh = st + atile_b<WM>();
     unsigned char* Al = Bh + BTILE_B;
     unsigned char* Bl = Al + atile_b<WM>();
     constexpr int XS = 16 * WM;
-    stash_x<X3>(s.x0, p.xr, p.xk, p.in_act, Ah, Al);
-    stash_x<X3>(s.x1, p.xr + XS, p.xk, p.in_act, Ah, Al);
-    stash_x<X3>(s.x2, p.xr + 2 * XS, p.xk, p.in_act, Ah, Al);
-    stash_x<X3>(s.x3, p.xr + 3 * XS, p.xk, p.in_act, Ah, Al);
+    stash_x<X3, SILU>(s.x0, p.xr, p.xk, Ah, Al);
+    stash_x<X3, SILU>(s.x1, p.xr + XS, p.xk, Ah, Al);
+    stash_x<X3, SILU>(s.x2, p.xr + 2 * XS, p.xk, Ah, Al);
+    stash_x<X3, SILU>(s.x3, p.xr + 3 * XS, p.xk, Ah, Al);
     *reinterpret_cast<uint4*>(Bh + swz(p.br, p.bc)) = s.w0;
     if constexpr (WM == 2) *reinterpret_cast<uint4*>(Bh + swz(p.br + 64, p.bc)) = s.w1;
     if constexpr (X3) {
@@ -197,7 +197,21 @@ __device__ __forceinline__ void compute(f32x16 (&acc)[2][2], const unsigned char
     }
 }
 
-template <bool X3, int WM>
+// Scheduling hint for one half-iteration: spread the conversion / LDS-write instructions of the stash between the MFMAs
+// instead of after them (the MFMA pipe runs 8 passes per instruction; the vector ALU is free meanwhile).
+template <bool X3>
+__device__ __forceinline__ void interleave() {
+    constexpr int N_MFMA = X3 ? 24 : 8;
+    constexpr int VALU_PER = X3 ? 4 : 6;
+#pragma unroll
+    for (int g = 0; g < N_MFMA; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0);     // a few VALU
+        if (g % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
+    }
+}
+
+template <bool X3, int WM, bool SILU>
 __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(const LinearArgs a, int tiles_n, int n_tiles) {
     constexpr int TM = 64 * WM, NT = 128 * WM;
     constexpr int STAGE_B = (X3 ? 2 : 1) * (atile_b<WM>() + BTILE_B);
@@ -247,20 +261,24 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(c
     unsigned char* buf0 = smem;
     unsigned char* buf1 = smem + STAGE_B;
     Stage<X3, WM> sa, sb;
+    // Fetches and stashes are unconditional (past the end they re-read the last K-step, which nobody multiplies): with a
+    // fixed number of loads in flight the compiler can wait for exactly the older register set and leave the newer one flying.
+    const int klast = (nk - 1) * TK;
     fetch<X3, WM>(sa, plan, 0);
     fetch<X3, WM>(sb, plan, TK);
-    stash<X3, WM>(sa, plan, buf0);
-    if (nk > 2) fetch<X3, WM>(sa, plan, 2 * TK);
+    stash<X3, WM, SILU>(sa, plan, buf0);
+    fetch<X3, WM>(sa, plan, min(2 * TK, klast));
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
-        const bool more = kt + 2 < nk;
         compute<X3, WM>(acc, buf0, wr, wc, fr, fc);
-        stash<X3, WM>(sb, plan, buf1);
-        if (more) fetch<X3, WM>(sb, plan, (kt + 3) * TK);
+        stash<X3, WM, SILU>(sb, plan, buf1);
+        interleave<X3>();
+        fetch<X3, WM>(sb, plan, min((kt + 3) * TK, klast));
         __syncthreads();
         compute<X3, WM>(acc, buf1, wr, wc, fr, fc);
-        if (more) stash<X3, WM>(sa, plan, buf0);
-        if (kt + 4 < nk) fetch<X3, WM>(sa, plan, (kt + 4) * TK);
+        stash<X3, WM, SILU>(sa, plan, buf0);
+        interleave<X3>();
+        fetch<X3, WM>(sa, plan, min((kt + 4) * TK, klast));
         __syncthreads();
     }
 
@@ -292,19 +310,24 @@ bool linear_big_ok(const LinearArgs& a) {
            (a.prec != PREC_BF16X3 || (a.Wlo && (reinterpret_cast<uintptr_t>(a.Wlo) & 15) == 0));
 }
 
-template <bool X3, int WM>
-static hipError_t launch_big(const LinearArgs& a, hipStream_t stream) {
+template <bool X3, int WM, bool SILU>
+static hipError_t launch_big2(const LinearArgs& a, hipStream_t stream) {
     constexpr int TM = 64 * WM;
     constexpr size_t smem = 2 * (X3 ? 2 : 1) * (size_t)(TM * ROW_B + BTILE_B);
     static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<X3, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_big_kernel<X3, WM, SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (attr != hipSuccess) return attr;
     const int tiles_m = (a.M + TM - 1) / TM, tiles_n = (a.N + TN - 1) / TN;
     const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
     if (n_tiles > (1 << 30)) return hipErrorInvalidValue;
     const int blocks = (int)((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL((linear_big_kernel<X3, WM>), dim3(blocks), dim3(128 * WM), smem, stream, a, tiles_n, (int)n_tiles);
+    hipLaunchKernelGGL((linear_big_kernel<X3, WM, SILU>), dim3(blocks), dim3(128 * WM), smem, stream, a, tiles_n, (int)n_tiles);
     return hipGetLastError();
+}
+
+template <bool X3, int WM>
+static hipError_t launch_big(const LinearArgs& a, hipStream_t stream) {
+    return a.in_act == ACT_SILU ? launch_big2<X3, WM, true>(a, stream) : launch_big2<X3, WM, false>(a, stream);
 }
 
 hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
