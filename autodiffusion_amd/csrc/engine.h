@@ -59,6 +59,16 @@ struct adx_engine {
     float* temb_table = nullptr;        // [n_steps][d_model] time-conditioning vector per step
     int schedule_version = 0;
 
+    // per-kernel timing of a call (adx_engine_profile): while enabled, calls run without graph capture and the marked
+    // launches are bracketed by events on the call's stream
+    bool profiling = false;
+    struct ProfSpan { hipEvent_t a, b; int stage; };
+    std::vector<ProfSpan> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+    void prof_begin(int stage, hipStream_t s);
+    void prof_end(hipStream_t s);
+    int profile_read(int stage, double* total_ms, int* count);     // synchronises; clears the collected spans when stage < 0
+
     // graphs
     hipStream_t cap_stream = nullptr;
     std::map<std::string, hipGraphExec_t> graphs;
@@ -90,7 +100,7 @@ struct adx_engine {
 
 template <class F>
 int adx_engine::run(const std::string& key, unsigned flags, hipStream_t stream, F&& body) {
-    if (flags & ADX_FLAG_NO_GRAPH) return body(stream);
+    if ((flags & ADX_FLAG_NO_GRAPH) || profiling) return body(stream);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
         if (!cap_stream) ADX_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));

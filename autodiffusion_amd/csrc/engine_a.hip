@@ -419,10 +419,16 @@ struct EngineA final : adx_engine {
         bool last_attn_done = false;      // ATT already holds the last encoder layer's attention for rows 0..T
         if (step >= 0 && fused) {
             // layer 0 and layer 1 up to its attention: three launches
+            prof_begin(1, s);
             ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s));
+            prof_end(s);
+            prof_begin(2, s);
             ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
+            prof_end(s);
             if (tail_ok && io.x_next && stepped) {
+                prof_begin(3, s);
                 ADX_TRY(launch_tail(B, x, io.z, steps_dev + step, io.x_next, out, s));
+                prof_end(s);
                 *stepped = true;
                 return ADX_OK;
             }
@@ -575,7 +581,9 @@ struct EngineA final : adx_engine {
         const bool cached = cfg.elide >= 2 && n_enc >= 2;
         if (cached) {
             ADX_TRY(set_time(B, temb_table, 0, s));          // defined (if irrelevant) values in row 0 before the cache pass
+            prof_begin(4, s);
             ADX_TRY(build_chunk_cache(B, s));
+            prof_end(s);
         }
         float* xc = XS0; float* xn = XS1;
         if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, s));

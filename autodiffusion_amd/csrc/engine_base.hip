@@ -27,6 +27,8 @@ using namespace adx;
 // ------------------------------------------------------------------------------------------ engine base
 adx_engine::~adx_engine() {
     drop_graphs();
+    for (const ProfSpan& p : prof_spans) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : prof_pool) (void)hipEventDestroy(e);
     for (auto& kv : params) {
         if (kv.second.f32) (void)hipFree(kv.second.f32);
         if (kv.second.bf16) (void)hipFree(kv.second.bf16);
@@ -142,6 +144,44 @@ int adx_engine::reserve(int batch) {
     ws_bytes = bytes;
     max_batch = batch;
     return carve_workspace(batch, false, &bytes);
+}
+
+void adx_engine::prof_begin(int stage, hipStream_t s) {
+    if (!profiling) return;
+    auto take = [&]() {
+        hipEvent_t e = nullptr;
+        if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    };
+    ProfSpan p{take(), take(), stage};
+    if (!p.a || !p.b) return;
+    (void)hipEventRecord(p.a, s);
+    prof_spans.push_back(p);
+}
+
+void adx_engine::prof_end(hipStream_t s) {
+    if (!profiling || prof_spans.empty()) return;
+    (void)hipEventRecord(prof_spans.back().b, s);
+}
+
+int adx_engine::profile_read(int stage, double* total_ms, int* count) {
+    ADX_HIP(hipSetDevice(device));
+    ADX_HIP(hipDeviceSynchronize());
+    double tot = 0.0;
+    int n = 0;
+    for (const ProfSpan& p : prof_spans) {
+        if (p.stage != stage) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { tot += ms; ++n; }
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    if (stage < 0) {
+        for (const ProfSpan& p : prof_spans) { prof_pool.push_back(p.a); prof_pool.push_back(p.b); }
+        prof_spans.clear();
+    }
+    return ADX_OK;
 }
 
 int adx_engine::set_schedule(const adx_step_coef* s, int n) {
@@ -277,6 +317,17 @@ ADX_API int adx_engine_set_tensor(adx_engine* e, const char* name, const float* 
 ADX_API int adx_engine_finalize(adx_engine* e) {
     if (!e) return fail(ADX_EINVAL, "finalize: null engine");
     return e->finalize();
+}
+
+ADX_API int adx_engine_profile(adx_engine* e, int enable) {
+    if (!e) return fail(ADX_EINVAL, "profile: null engine");
+    e->profiling = enable != 0;
+    return ADX_OK;
+}
+
+ADX_API int adx_engine_profile_read(adx_engine* e, int stage, double* total_ms, int* count) {
+    if (!e) return fail(ADX_EINVAL, "profile_read: null engine");
+    return e->profile_read(stage, total_ms, count);
 }
 
 ADX_API int adx_engine_reserve(adx_engine* e, int max_batch) {

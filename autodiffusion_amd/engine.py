@@ -116,6 +116,16 @@ class Engine:
         """Launch one kernel stage of a variant-A step on the current workspace (timing aid)."""
         check(self.lib.adx_debug_stage_a(self.h, int(batch), int(stage), int(iters), current_stream()), "adx_debug_stage_a")
 
+    def profile(self, enable: bool):
+        """Time the marked kernels of the following calls with events (calls then run without graph capture)."""
+        check(self.lib.adx_engine_profile(self.h, int(bool(enable))), "adx_engine_profile")
+
+    def profile_read(self, stage: int) -> Tuple[float, int]:
+        """(summed milliseconds, launches) of one stage since the last clear; stage -1 clears."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(self.lib.adx_engine_profile_read(self.h, int(stage), C.byref(ms), C.byref(n)), "adx_engine_profile_read")
+        return ms.value, n.value
+
     def sample_dit(self, state, noise, flags: int, out: Optional[torch.Tensor] = None):
         B, S = state.shape[0], state.shape[1]
         n_noise = 0 if noise is None else noise.shape[0]

@@ -165,6 +165,14 @@ int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transitio
 int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
                    const float* init_x, const float* noise, int n_noise, float* out, unsigned flags, void* stream);
 
+/* No counterpart in the reference: per-kernel timing of real calls.  While enabled, sampling calls on this engine run
+ * without graph capture and bracket their marked launches with events on the caller's stream; stages of variant A:
+ * 1 fused encoder rows, 2 last-layer attention, 3 fused tail, 4 per-chunk cache build.  adx_engine_profile_read
+ * synchronises the device and returns the summed duration and the number of launches of one stage; stage -1 clears
+ * what was collected. */
+int adx_engine_profile(adx_engine* e, int enable);
+int adx_engine_profile_read(adx_engine* e, int stage, double* total_ms, int* count);
+
 /* No counterpart in the reference: launches ONE kernel stage of a variant-A sampling step `iters` times on the
  * engine's current workspace (after a generate/sample call with the same B), so a benchmark can time that kernel
  * alone with events on `stream`.  stage: 0 time-token attention, 1 fused encoder rows, 2 last-layer attention,
