@@ -36,8 +36,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 def build_model(dev, precision="bf16"):
     from autodiffusion_amd import refiner, synth
-    cfg = refiner.refiner_config(frame_stack=FS, diffusion_timesteps=N_TRAIN, sampling_timesteps=N_SAMPLE, objective="pred_noise",
-                                 beta_schedule="cosine", ddim=0.0, normalize=True, residual=False, precision=precision)
+    cfg = refiner.refiner_config(frame_stack=FS, diffusion_timesteps=N_TRAIN, sampling_timesteps=N_SAMPLE if N_SAMPLE < N_TRAIN else None,
+                                 objective="pred_noise", beta_schedule="cosine", ddim=0.0, normalize=True, residual=False, precision=precision)
     da = refiner.DiffusionAugmentation(cfg)
     synth.reference_init_(da, 11)
     return da.to(dev).eval()
@@ -47,7 +47,8 @@ def make_inputs(B, row0, dev):
     from autodiffusion_amd import synth
     maps = synth.maps_info(B, 7, row0).to(dev)
     prior = synth.trajectory_prior(B, 7, row0).to(dev)
-    noise = synth.noise(B, (80 // FS, N_SAMPLE), (FS, 4), 1234, row0).to(dev)
+    n_draws = N_SAMPLE if N_SAMPLE < N_TRAIN else N_TRAIN      # DDIM (eta 0) reads only the first; DDPM one per step
+    noise = synth.noise(B, (80 // FS, n_draws), (FS, 4), 1234, row0).to(dev)
     return maps, prior, noise
 
 
@@ -200,6 +201,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 4096 for the refiner)")
     ap.add_argument("--workload", default="refiner", choices=["refiner"] + sorted(DIT_WORKLOADS),
                     help="refiner = the headline configuration; the DiT decoder workloads run on one GPU only")
+    ap.add_argument("--frame-stack", type=int, default=0, help="refiner: points per chunk (default 10; 80 = whole trajectory)")
+    ap.add_argument("--n-train", type=int, default=0, help="refiner: training timesteps (default 100)")
+    ap.add_argument("--n-sample", type=int, default=0, help="refiner: sampling steps (default 50; equal to --n-train = DDPM loop)")
     ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,6 +220,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    global FS, N_TRAIN, N_SAMPLE, L_COND
+    FS, N_TRAIN, N_SAMPLE = args.frame_stack or FS, args.n_train or N_TRAIN, args.n_sample or N_SAMPLE
+    L_COND = 1 + 788 + 2 * FS
     if args.workload != "refiner":
         if world > 1:
             raise SystemExit("the DiT workloads are single-GPU measurements")
@@ -257,8 +264,9 @@ def main():
             "metric": "denoised trajectories/sec (8s, 80-pt)", "value": round(total * args.steps / dt, 2), "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": "strDiffDiT-style refiner (enc/dec Transformer d=32, 809 cond tokens), frame_stack 10 x 8 chunks, "
-                                   "DDIM 50 of 100 steps, random init, synthetic nuPlan-shaped conditioning",
+            "config": {"workload": f"strDiffDiT-style refiner (enc/dec Transformer d=32, {L_COND} cond tokens), frame_stack {FS} x {80 // FS} chunks, "
+                                   + (f"DDIM {N_SAMPLE} of {N_TRAIN} steps" if N_SAMPLE < N_TRAIN else f"DDPM {N_TRAIN} steps")
+                                   + ", random init, synthetic nuPlan-shaped conditioning",
                        "batch_per_gpu": B, "global_batch": total, "denoiser_calls_per_step": (80 // FS) * N_SAMPLE,
                        "parallelism": f"dp{world}",
                        "precision": {"bf16x3": "bf16 MFMA on split (hi+lo) operands, f32 accumulate; trajectory path and scheduler f32",
@@ -266,7 +274,8 @@ def main():
                                      "fp32": "f32 MFMA"}[args.precision]},
         }
         if world == 1:
-            line["roofline"] = roofline(da, B, step)
+            if FS == 10:                                      # the fused kernels the roofline entry describes need T + 1 <= 16
+                line["roofline"] = roofline(da, B, step)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

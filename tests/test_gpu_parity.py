@@ -185,6 +185,37 @@ def test_variant_a_single_call(dev, golden, tag, fs, flat, elide):
     assert e < GATE
 
 
+@pytest.mark.parametrize("kind", ["ddim", "ddpm"])
+def test_explicit_flattened_chunk_loop(dev, kind):
+    """ExplicitDiT: flattened chunks (horizon 1, 40 channels), diffusers-style steps, un-normalised prior, data_mean/std
+    on the output.  Checked against the oracle's restatement (parity unpinned: the reference cannot run this variant)."""
+    from autodiffusion_amd import explicit, synth
+    from oracle import nets, sampling, schedules as osched
+    from test_oracle_golden import variant_a_sd
+    cfg = explicit.explicit_config(frame_stack=10, num_train_timesteps=100, num_inference_steps=10, kind=kind)
+    m = explicit.ExplicitDiT(cfg)
+    synth.fill_module_(m, WSEED)
+    m = m.to(dev).eval()
+    B = 3
+    maps = synth.maps_info(B, ISEED)
+    prior = synth.trajectory_prior(B, ISEED)
+    noise = synth.noise(B, (8, 11), (1, 40), NSEED)
+    out = m.generate(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), noise=noise.to(dev))["traj_logits"].cpu()
+    assert out.shape == (B, 80, 4)
+    sd = {k[len("diffusion.diffusion."):]: v.detach().float().cpu() for k, v in m.state_dict().items() if k.startswith("diffusion.diffusion.")}
+    ac = np.cumprod(1.0 - osched.squaredcos_cap_v2(100).astype(np.float64))
+
+    def denoise(x, t, tran, pri):
+        tt = torch.full((x.shape[0],), int(t), dtype=torch.long)
+        return nets.variant_a_forward(sd, x, tt, maps, tran, pri)
+    ref = sampling.explicit_generate(denoise, ac, 10, prior, m.init_x.detach().cpu(), noise, 10, cfg.data_mean, cfg.data_std, kind)
+    e = rel_err(out, ref)
+    print(f"ExplicitDiT {kind}: rel err {e:.2e}")
+    assert e < GATE
+    with pytest.raises(ValueError):
+        m.generate(trajectory_prior=prior[:, :75].to(dev), maps_info=maps.to(dev))
+
+
 def test_variant_a_state_dict_layout(dev):
     """The parameter/buffer names are the reference's (110 entries for fs=10)."""
     m = make_a(10)

@@ -161,6 +161,14 @@ def test_module_layouts_match_reference_names():
     m = dit.Transformer_TrajDiffusionModel(dit.dit_config(256, 4, 8, "DiT"))
     n = sum(p.numel() for p in m.parameters())
     assert abs(n - 13.1e6) < 0.1e6, n                                                   # 13.1 M measured on the reference
+    from autodiffusion_amd import explicit
+    ex = explicit.ExplicitDiT(explicit.explicit_config(frame_stack=10))
+    ek = set(ex.state_dict().keys())
+    for k in ("init_x", "data_mean", "data_std", "diffusion.diffusion.cond_pos_emb", "diffusion.diffusion.head.weight"):
+        assert k in ek, k
+    assert tuple(ex.diffusion.diffusion.cond_pos_emb.shape) == (1, 791, 32)               # the reference's "# 791"
+    assert tuple(ex.init_x.shape) == (40,)
+    assert [int(r[0]) for r in ex.diffusion.schedule_rows()] == [90, 80, 70, 60, 50, 40, 30, 20, 10, 0]
     with pytest.raises(ValueError):
         dit.Transformer_TrajDiffusionModel(dit.dit_config(64, 2, 4, "DDPM"))
     with pytest.raises(AssertionError):
