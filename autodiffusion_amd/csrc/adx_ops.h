@@ -83,16 +83,32 @@ hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream);
 // Q/O/state address rows exactly as in AttentionArgs (Sq rows per batch item).  head_dim 4.
 hipError_t attention_merge_key(const AttentionArgs& a, hipStream_t stream);
 
-// Attention of query rows that every batch item shares (the time token under each scheduler step: row s of `table`
-// holds its q | k | v, 32 floats each) over Skv keys of the item plus the row's own key.  O is [NS][B][32].  8 heads x 4.
-struct TimeRowsArgs {
-    const float* table = nullptr; int64_t ldt = 0;
+// Attention of a few query rows per item over Skv keys of the item, a thread per (head, query), keys walked through
+// an LDS tile shared by 32 queries.  8 heads x 4.  Two uses:
+//  * query rows shared by every item (q_batch_stride 0; the time token under each scheduler step): row s of Q holds
+//    q | k | v (own = 1: the row's own key opens the softmax) and O[(s * B + b) * 32] receives the normalised output;
+//  * per-item rows (own = 0) whose running softmax state {m, l, o[4]} is stored (state != nullptr), heads permuted as in
+//    AttentionArgs::state.
+struct RowsAttnArgs {
+    const float* Q = nullptr; int64_t ldq = 0, q_batch_stride = 0; int own = 0;
     const float* K = nullptr; const float* V = nullptr; int64_t ldk = 0, k_batch_stride = 0;
     float* O = nullptr;
+    float* state = nullptr; int64_t state_ld = 0, state_batch_stride = 0;
     int B = 0, NS = 0, Skv = 0;
     float scale = 1.f;
 };
-hipError_t attention_time_rows(const TimeRowsArgs& a, hipStream_t stream);
+hipError_t attention_rows(const RowsAttnArgs& a, hipStream_t stream);
+
+// state_out[b, r, h] = state_in[b, r, h] with NK more keys folded in (keys/values of rows K/V[b, 0..NK-1]); Q rows as in
+// AttentionArgs, states in the permuted-head layout, row stride state_ld.  NK <= 64, 8 heads x 4.
+struct FoldKeysArgs {
+    const float* Q = nullptr; int64_t ldq = 0, q_batch_stride = 0;
+    const float* K = nullptr; const float* V = nullptr; int64_t ldk = 0, k_batch_stride = 0;
+    const float* state_in = nullptr; float* state_out = nullptr; int64_t state_ld = 0, state_batch_stride = 0;
+    int B = 0, Sq = 0, NK = 0;
+    float scale = 1.f;
+};
+hipError_t attention_fold_keys(const FoldKeysArgs& a, hipStream_t stream);
 
 // Fused per-row pipeline of the variant-A encoder (d_model 32, 8 heads, FFN 128); see fused_a.hip.
 // For every conditioning row: fold the time-token key (key0 = [k(32), v(32)]) into the cached layer-0 softmax state

@@ -47,6 +47,9 @@ struct EngineA final : adx_engine {
     float *QKV0 = nullptr, *ST = nullptr, *PK = nullptr, *tqkv0 = nullptr;
     // fused path: tx0[s] = encoder input of the time token at step s; ATT0[s][b] = its layer-0 attention output
     float *tx0 = nullptr, *ATT0 = nullptr;
+    // per-call map cache: states of the map queries over the map keys (the maps do not change between chunks)
+    bool split_cache = false;
+    float* STM = nullptr;
     bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
     // elide level 3: the per-row pipeline between the two encoder attentions runs as one fused kernel
     bool fused = false;
@@ -81,6 +84,8 @@ struct EngineA final : adx_engine {
         if (cfg.elide >= 2 && !fast4) cfg.elide = 1;
         fused = cfg.elide >= 3 && n_enc == 2;
         tail_ok = fused && T + 1 <= 12 && Cin == Cout && Cin <= 64 && (Cin % 4) == 0 && n_dec <= 4;
+        const char* whole = getenv("ADX_CHUNK_CACHE_WHOLE");   // tuning knob: rebuild the whole layer-0 cache per chunk
+        split_cache = fused && fast4 && cfg.map_cond && nmaps > 0 && 2 * NP <= 64 && !(whole && whole[0] == '1');
         const char* no_mfma = getenv("ADX_TAIL_VALU");       // tuning knob: force the VALU form of the tail
         tail_mfma_ok = tail_ok && Cin == 4 && !(no_mfma && no_mfma[0] == '1');
     }
@@ -134,6 +139,7 @@ struct EngineA final : adx_engine {
         if (fused) {
             take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
             take(&ATT0, (size_t)B * std::max<size_t>(steps.size(), 1) * d);
+            if (split_cache) take(&STM, BL * H * 6);
         }
         *bytes = off;
         return ADX_OK;
@@ -310,27 +316,72 @@ struct EngineA final : adx_engine {
         return ADX_OK;
     }
 
-    // Per chunk: q/k/v of all conditioning rows under layer 0 and the softmax state of rows >= 1 over keys >= 1.
-    int build_chunk_cache(int B, hipStream_t s) {
+    // Layer-0 q/k/v of `rows` conditioning rows per item starting at row `row0` (LayerNorm + in_proj)
+    int project_rows0(int B, int row0, int rows, hipStream_t s) {
         const std::string p = "encoder.layers.0";
+        const RowMap map{rows, L, row0};
+        ADX_TRY(ln_rows(X0, H1, p + ".norm1", B * rows, map, s));
+        LinearArgs a = lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV0, 3 * d, B * rows);
+        a.xmap = map; a.ymap = map;
+        ADX_HIP(linear(a, s));
+        return ADX_OK;
+    }
+
+    // Once per call (the map tokens do not change between chunks): their layer-0 q/k/v and the softmax state of every map
+    // query over all map keys.
+    int build_map_cache(int B, hipStream_t s) {
+        if (!split_cache) return ADX_OK;
         const int dh = d / H;
-        ADX_TRY(ln_rows(X0, H1, p + ".norm1", B * L, RowMap{}, s));
-        ADX_HIP(linear(lin(H1, d, p + ".self_attn.in_proj_weight", 0, 3 * d, d, p + ".self_attn.in_proj_bias", QKV0, 3 * d, B * L), s));
+        ADX_TRY(project_rows0(B, 1, nmaps, s));
         AttentionArgs at;
         at.Q = QKV0 + 3 * d; at.K = QKV0 + 3 * d + d; at.V = QKV0 + 3 * d + 2 * d;
         at.ldq = at.ldk = at.ldv = 3 * d;
         at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)L * 3 * d;
-        at.B = B; at.H = H; at.Sq = L - 1; at.Skv = L - 1; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
-        at.state = ST + H * 6; at.state_ld = H * 6; at.state_batch_stride = (int64_t)L * H * 6;
+        at.B = B; at.H = H; at.Sq = nmaps; at.Skv = nmaps; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
+        at.state = STM + H * 6; at.state_ld = H * 6; at.state_batch_stride = (int64_t)L * H * 6;
         ADX_HIP(attention(at, s));
+        return ADX_OK;
+    }
+
+    // Per chunk: q/k/v of the conditioning rows under layer 0 and the softmax state of rows >= 1 over keys >= 1.
+    // With the per-call map cache only the 2 NP transition / prior rows are new: their keys are folded into the map
+    // queries' states and their own states are computed over all keys.
+    int build_chunk_cache(int B, hipStream_t s) {
+        const int dh = d / H;
+        const float scale = 1.0f / sqrtf((float)dh);
+        if (split_cache) {
+            const int r0 = 1 + nmaps, nr = 2 * NP;
+            ADX_TRY(project_rows0(B, r0, nr, s));
+            FoldKeysArgs f;
+            f.Q = QKV0 + 3 * d; f.ldq = 3 * d; f.q_batch_stride = (int64_t)L * 3 * d;
+            f.K = QKV0 + (int64_t)r0 * 3 * d + d; f.V = QKV0 + (int64_t)r0 * 3 * d + 2 * d; f.ldk = 3 * d; f.k_batch_stride = (int64_t)L * 3 * d;
+            f.state_in = STM + H * 6; f.state_out = ST + H * 6; f.state_ld = H * 6; f.state_batch_stride = (int64_t)L * H * 6;
+            f.B = B; f.Sq = nmaps; f.NK = nr; f.scale = scale;
+            ADX_HIP(attention_fold_keys(f, s));
+            RowsAttnArgs ra;
+            ra.Q = QKV0 + (int64_t)r0 * 3 * d; ra.ldq = 3 * d; ra.q_batch_stride = (int64_t)L * 3 * d; ra.own = 0;
+            ra.K = QKV0 + 3 * d + d; ra.V = QKV0 + 3 * d + 2 * d; ra.ldk = 3 * d; ra.k_batch_stride = (int64_t)L * 3 * d;
+            ra.state = ST + (int64_t)r0 * H * 6; ra.state_ld = H * 6; ra.state_batch_stride = (int64_t)L * H * 6;
+            ra.B = B; ra.NS = nr; ra.Skv = L - 1; ra.scale = scale;
+            ADX_HIP(attention_rows(ra, s));
+        } else {
+            ADX_TRY(project_rows0(B, 0, L, s));
+            AttentionArgs at;
+            at.Q = QKV0 + 3 * d; at.K = QKV0 + 3 * d + d; at.V = QKV0 + 3 * d + 2 * d;
+            at.ldq = at.ldk = at.ldv = 3 * d;
+            at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)L * 3 * d;
+            at.B = B; at.H = H; at.Sq = L - 1; at.Skv = L - 1; at.dh = dh; at.dv = dh; at.scale = scale; at.mask_off = -1;
+            at.state = ST + H * 6; at.state_ld = H * 6; at.state_batch_stride = (int64_t)L * H * 6;
+            ADX_HIP(attention(at, s));
+        }
         if (fused) {
             ADX_HIP(enc_rows_pack(rows_args(B, 0), s));
             // the time token's attention for every step of the chunk in one pass over the keys
-            TimeRowsArgs tr;
-            tr.table = tqkv0; tr.ldt = 3 * d;
+            RowsAttnArgs tr;
+            tr.Q = tqkv0; tr.ldq = 3 * d; tr.q_batch_stride = 0; tr.own = 1;
             tr.K = QKV0 + 3 * d + d; tr.V = QKV0 + 3 * d + 2 * d; tr.ldk = 3 * d; tr.k_batch_stride = (int64_t)L * 3 * d;
-            tr.O = ATT0; tr.B = B; tr.NS = (int)steps.size(); tr.Skv = L - 1; tr.scale = at.scale;
-            ADX_HIP(attention_time_rows(tr, s));
+            tr.O = ATT0; tr.B = B; tr.NS = (int)steps.size(); tr.Skv = L - 1; tr.scale = scale;
+            ADX_HIP(attention_rows(tr, s));
         }
         return ADX_OK;
     }
@@ -531,7 +582,7 @@ struct EngineA final : adx_engine {
 
     // Launch ONE stage of a sampling step on the current workspace contents, `iters` times (for timing a kernel in
     // isolation with events on `s`).  Stages: 0 time-token attention, 1 fused encoder rows, 2 last-layer attention,
-    // 3 fused tail, 4 per-chunk cache build.  Needs a previous generate/sample call with the same B.
+    // 3 fused tail, 4 per-chunk cache build, 5 per-call map cache build.  Needs a previous generate/sample call with the same B.
     int debug_stage(int B, int stage, int iters, hipStream_t s) {
         if (!finalized || steps.empty() || B > max_batch || !fused) { set_error("debug_stage: engine not ready (needs elide 3, a schedule and a prior call)"); return ADX_ESTATE; }
         for (int it = 0; it < iters; ++it) {
@@ -543,6 +594,7 @@ struct EngineA final : adx_engine {
                 if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
                 ADX_TRY(launch_tail(B, XS0, nullptr, steps_dev, XS1, MOUT, s));
             } else if (stage == 4) ADX_TRY(build_chunk_cache(B, s));
+            else if (stage == 5) ADX_TRY(build_map_cache(B, s));
             else { set_error("debug_stage: unknown stage"); return ADX_EINVAL; }
         }
         return ADX_OK;
@@ -636,6 +688,7 @@ struct EngineA final : adx_engine {
                  (const void*)noise, n_noise, (void*)out, (void*)trace_x, (void*)trace_out, flags, schedule_version);
         return run(key, flags, s, [&](hipStream_t cs) -> int {
             ADX_TRY(embed_maps(B, maps, cs));
+            ADX_TRY(build_map_cache(B, cs));
             return sample_body(B, tran, prior, noise, n_noise, out, (int64_t)T * Cin, trace_x, trace_out, flags, cs);
         });
     }
@@ -653,6 +706,9 @@ struct EngineA final : adx_engine {
                  (const void*)init_x, (const void*)noise, n_noise, (void*)out, flags, schedule_version);
         return run(key, flags, s, [&](hipStream_t cs) -> int {
             ADX_TRY(embed_maps(B, maps, cs));
+            prof_begin(5, cs);
+            ADX_TRY(build_map_cache(B, cs));
+            prof_end(cs);
             for (int c = 0; c < n_chunks; ++c) {
                 ADX_HIP(copy2d(prior_full + (int64_t)c * chunk, (int64_t)S * 4, 0, PRAW, chunk, B, chunk, cs));
                 if (c == 0) ADX_HIP(copy2d(init_x, chunk, 1, TRAW, chunk, B, chunk, cs));

@@ -553,21 +553,25 @@ hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Shared query rows (see TimeRowsArgs): a thread owns (head, query); a workgroup covers 32 queries of one item and
-// walks the item's keys through a 64-row LDS tile that all 32 queries reuse.
-__global__ __launch_bounds__(256) void attn_time_rows_kernel(const TimeRowsArgs a) {
+// A few query rows per item (see RowsAttnArgs): a thread owns (head, query); a workgroup covers 32 queries of one item
+// and walks the item's keys through a 64-row LDS tile that all 32 queries reuse.
+__global__ __launch_bounds__(256) void attn_rows_kernel(const RowsAttnArgs a) {
     constexpr int KT = 64;
     __shared__ __attribute__((aligned(16))) float4 KVs[KT][16];      // row: k (8 float4), v (8 float4)
     const int b = blockIdx.y, tid = threadIdx.x, h = tid & 7;
     const int s = min((int)blockIdx.x * 32 + (tid >> 3), a.NS - 1);
-    const float* row = a.table + (int64_t)s * a.ldt;
+    const float* row = a.Q + (int64_t)b * a.q_batch_stride + (int64_t)s * a.ldq;
     const float f = a.scale * LOG2E;
     float4 q = *reinterpret_cast<const float4*>(row + 4 * h);
     q.x *= f; q.y *= f; q.z *= f; q.w *= f;
-    // the row's own key opens the running softmax
-    const float4 k0 = *reinterpret_cast<const float4*>(row + 32 + 4 * h);
-    float4 o = *reinterpret_cast<const float4*>(row + 64 + 4 * h);
-    float m = fmaf(q.x, k0.x, fmaf(q.y, k0.y, fmaf(q.z, k0.z, q.w * k0.w))), l = 1.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = -INFINITY, l = 0.f;
+    if (a.own) {                                                     // the row's own key opens the running softmax
+        const float4 k0 = *reinterpret_cast<const float4*>(row + 32 + 4 * h);
+        o = *reinterpret_cast<const float4*>(row + 64 + 4 * h);
+        m = fmaf(q.x, k0.x, fmaf(q.y, k0.y, fmaf(q.z, k0.z, q.w * k0.w)));
+        l = 1.f;
+    }
     const float* Kb = a.K + (int64_t)b * a.k_batch_stride;
     const float* Vb = a.V + (int64_t)b * a.k_batch_stride;
     for (int j0 = 0; j0 < a.Skv; j0 += KT) {
@@ -591,14 +595,64 @@ __global__ __launch_bounds__(256) void attn_time_rows_kernel(const TimeRowsArgs 
         }
     }
     if ((int)blockIdx.x * 32 + (tid >> 3) < a.NS) {
-        const float inv = rcp_fast(l);
-        *reinterpret_cast<float4*>(a.O + ((int64_t)s * a.B + b) * 32 + 4 * h) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        if (a.state) {
+            float* Sp = a.state + (int64_t)b * a.state_batch_stride + (int64_t)s * a.state_ld + ((h & 1) * 4 + (h >> 1)) * 6;
+            float2* S2 = reinterpret_cast<float2*>(Sp);                 // 24-byte records: 8-byte aligned
+            S2[0] = make_float2(m, l); S2[1] = make_float2(o.x, o.y); S2[2] = make_float2(o.z, o.w);
+        } else {
+            const float inv = rcp_fast(l);
+            *reinterpret_cast<float4*>(a.O + ((int64_t)s * a.B + b) * 32 + 4 * h) = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        }
     }
 }
 
-hipError_t attention_time_rows(const TimeRowsArgs& a, hipStream_t stream) {
-    if (a.B <= 0 || a.NS <= 0 || a.Skv < 0 || !a.table || !a.K || !a.V || !a.O) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_time_rows_kernel, dim3((a.NS + 31) / 32, a.B), dim3(256), 0, stream, a);
+hipError_t attention_rows(const RowsAttnArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.NS <= 0 || a.Skv < 0 || !a.Q || !a.K || !a.V || (!a.O && !a.state) || (a.state && (a.state_ld & 1))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_rows_kernel, dim3((a.NS + 31) / 32, a.B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// Fold NK more keys into stored softmax states (see FoldKeysArgs): a thread owns (head, query row); the item's NK key /
+// value rows sit in LDS.
+__global__ __launch_bounds__(256) void attn_fold_keys_kernel(const FoldKeysArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 KVs[64][16];
+    const int b = blockIdx.y, tid = threadIdx.x, h = tid & 7;
+    const int r = (int)blockIdx.x * 32 + (tid >> 3);
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride;
+    const float* Vb = a.V + (int64_t)b * a.k_batch_stride;
+    for (int i = tid; i < a.NK * 16; i += 256) {
+        const int j = i >> 4, c = i & 15;
+        KVs[j][c] = *reinterpret_cast<const float4*>((c < 8 ? Kb : Vb) + (int64_t)j * a.ldk + 4 * (c & 7));
+    }
+    __syncthreads();
+    if (r >= a.Sq) return;
+    const float f = a.scale * LOG2E;
+    float4 q = *reinterpret_cast<const float4*>(a.Q + (int64_t)b * a.q_batch_stride + (int64_t)r * a.ldq + 4 * h);
+    q.x *= f; q.y *= f; q.z *= f; q.w *= f;
+    const int64_t so = (int64_t)b * a.state_batch_stride + (int64_t)r * a.state_ld + ((h & 1) * 4 + (h >> 1)) * 6;
+    const float2* I2 = reinterpret_cast<const float2*>(a.state_in + so);       // 24-byte records: 8-byte aligned
+    const float2 ml = I2[0], o01 = I2[1], o23 = I2[2];
+    float4 o = make_float4(o01.x, o01.y, o23.x, o23.y);
+    float m = ml.x, l = ml.y;
+#pragma unroll 4
+    for (int j = 0; j < a.NK; ++j) {
+        const float4 kk = KVs[j][h], vv = KVs[j][8 + h];
+        const float sc = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+        const float mn = fmaxf(m, sc);
+        const float al = exp2_fast(m - mn), p = exp2_fast(sc - mn);
+        l = fmaf(l, al, p);
+        o.x = fmaf(o.x, al, p * vv.x); o.y = fmaf(o.y, al, p * vv.y);
+        o.z = fmaf(o.z, al, p * vv.z); o.w = fmaf(o.w, al, p * vv.w);
+        m = mn;
+    }
+    float2* O2 = reinterpret_cast<float2*>(a.state_out + so);
+    O2[0] = make_float2(m, l); O2[1] = make_float2(o.x, o.y); O2[2] = make_float2(o.z, o.w);
+}
+
+hipError_t attention_fold_keys(const FoldKeysArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.Sq <= 0 || a.NK <= 0 || a.NK > 64 || !a.Q || !a.K || !a.V || !a.state_in || !a.state_out || (a.state_ld & 1))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_fold_keys_kernel, dim3((a.Sq + 31) / 32, a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

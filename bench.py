@@ -82,7 +82,7 @@ def roofline(da, B, step):
     other kernels of a call from the same pass.
     """
     eng = da.diffusion.diffusion.model.engine()
-    names = {1: "enc_rows", 2: "last_layer_attention", 3: "tail", 4: "chunk_cache_build"}
+    names = {1: "enc_rows", 2: "last_layer_attention", 3: "tail", 4: "chunk_cache_build", 5: "map_cache_build"}
     eng.profile(True)
     try:
         eng.profile_read(-1)

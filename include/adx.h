@@ -167,7 +167,8 @@ int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* ma
 
 /* No counterpart in the reference: per-kernel timing of real calls.  While enabled, sampling calls on this engine run
  * without graph capture and bracket their marked launches with events on the caller's stream; stages of variant A:
- * 1 fused encoder rows, 2 last-layer attention, 3 fused tail, 4 per-chunk cache build.  adx_engine_profile_read
+ * 1 fused encoder rows, 2 last-layer attention, 3 fused tail, 4 per-chunk cache build, 5 per-call map cache build.
+ * adx_engine_profile_read
  * synchronises the device and returns the summed duration and the number of launches of one stage; stage -1 clears
  * what was collected. */
 int adx_engine_profile(adx_engine* e, int enable);
@@ -176,7 +177,7 @@ int adx_engine_profile_read(adx_engine* e, int stage, double* total_ms, int* cou
 /* No counterpart in the reference: launches ONE kernel stage of a variant-A sampling step `iters` times on the
  * engine's current workspace (after a generate/sample call with the same B), so a benchmark can time that kernel
  * alone with events on `stream`.  stage: 0 time-token attention, 1 fused encoder rows, 2 last-layer attention,
- * 3 fused tail, 4 per-chunk attention-state build. */
+ * 3 fused tail, 4 per-chunk attention-state build, 5 per-call map-token cache build. */
 int adx_debug_stage_a(adx_engine* e, int B, int stage, int iters, void* stream);
 
 /* DiffusionWrapper.sample_forward / p_sample_loop -- models/diffusion_loss/diffusion_decoder.py:377-446.

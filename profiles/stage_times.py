@@ -17,9 +17,9 @@ out = torch.empty(B, 80, 4, device=dev)
 da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
 torch.cuda.synchronize()
 eng = da.diffusion.diffusion.model.engine()
-names = {1: "fused encoder rows", 2: "last-layer attention", 3: "fused tail", 4: "chunk cache build"}
+names = {1: "fused encoder rows", 2: "last-layer attention", 3: "fused tail", 4: "chunk cache build", 5: "map cache build"}
 for stage, name in names.items():
-    iters = 3 if stage == 4 else 20
+    iters = 3 if stage >= 4 else 20
     eng.debug_stage_a(B, stage, 2)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
