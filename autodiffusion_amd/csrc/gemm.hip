@@ -301,6 +301,169 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(c
     }
 }
 
+// ============================================================================================================
+// Wave-specialised form for large problems: a 256x128 tile per 512-thread workgroup.  Waves 0-3 only multiply (each a
+// 128x64 sub-tile, 4x2 accumulators = 128 VGPRs, no vector-ALU work in the loop); waves 4-7 only stage: fetch the fp32
+// X rows and bf16 W rows two K-steps ahead, convert / split them and write the LDS image of the next K-step.  A SIMD
+// hosts one wave of each kind (waves are placed on SIMDs cyclically), so the conversion work and the LDS writes run
+// under the other wave's MFMAs instead of between them.  One barrier per K-step.
+// ============================================================================================================
+constexpr int WS_TM = 256;
+constexpr int WS_ATILE = WS_TM * ROW_B;           // 16 KB
+
+template <bool X3> struct WsStage { float4 x[8]; uint4 w[2]; uint4 l[2]; };
+
+template <bool X3, bool SILU>
+__global__ __launch_bounds__(512, 1) void linear_ws_kernel(const LinearArgs a, int tiles_n, int n_tiles) {
+    constexpr int STAGE_B = (X3 ? 2 : 1) * (WS_ATILE + BTILE_B);          // [A_hi][B_hi][A_lo][B_lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STAGE_B
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int m0 = (tile / tiles_n) * WS_TM, n0 = (tile % tiles_n) * TN;
+    const int M = a.M, N = a.N, K = a.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nk = K / TK;
+    unsigned char* buf0 = smem;
+    unsigned char* buf1 = smem + STAGE_B;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers (256 threads)
+        const int pt = tid - 256;
+        const int xr = pt >> 3, xk = (pt & 7) * 4;                // X rows xr + 32 i (i < 8), floats xk..xk+3
+        const int br = pt >> 2, bc = pt & 3;                      // W rows br + 64 i (i < 2), chunk bc
+        const float* xp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xp[i] = a.X + row_of(a.xmap, min(m0 + xr + 32 * i, M - 1)) * a.ldx + xk;
+        const unsigned short* wp[2];
+        const unsigned short* lp[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t off = (int64_t)min(n0 + br + 64 * i, N - 1) * K + bc * 8;
+            wp[i] = reinterpret_cast<const unsigned short*>(a.W) + off;
+            lp[i] = X3 ? reinterpret_cast<const unsigned short*>(a.Wlo) + off : nullptr;
+        }
+        auto fetch_ws = [&](WsStage<X3>& g, int k0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g.x[i] = *reinterpret_cast<const float4*>(xp[i] + k0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                g.w[i] = *reinterpret_cast<const uint4*>(wp[i] + k0);
+                if constexpr (X3) g.l[i] = *reinterpret_cast<const uint4*>(lp[i] + k0);
+            }
+        };
+        auto stash_ws = [&](const WsStage<X3>& g, unsigned char* st) {
+            unsigned char* Ah = st;
+            unsigned char* Bh = st + WS_ATILE;
+            unsigned char* Al = Bh + BTILE_B;
+            unsigned char* Bl = Al + WS_ATILE;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) stash_x<X3, SILU>(g.x[i], xr + 32 * i, xk, Ah, Al);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<uint4*>(Bh + swz(br + 64 * i, bc)) = g.w[i];
+                if constexpr (X3) *reinterpret_cast<uint4*>(Bl + swz(br + 64 * i, bc)) = g.l[i];
+            }
+        };
+        const int klast = (nk - 1) * TK;
+        WsStage<X3> ga, gb;
+        fetch_ws(ga, 0);
+        fetch_ws(gb, TK);
+        stash_ws(ga, buf0);
+        fetch_ws(ga, min(2 * TK, klast));
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            stash_ws(gb, buf1);
+            fetch_ws(gb, min((kt + 3) * TK, klast));
+            __syncthreads();
+            stash_ws(ga, buf0);
+            fetch_ws(ga, min((kt + 4) * TK, klast));
+            __syncthreads();
+        }
+        __syncthreads();                                          // pairs with the consumers' barrier before the epilogue
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers (waves 0-3 as 2x2, 128x64 each)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fc = lane >> 5;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute_ws = [&](const unsigned char* st) {
+        const unsigned char* Bh = st + WS_ATILE;
+        const unsigned char* Al = Bh + BTILE_B;
+        const unsigned char* Bl = Al + WS_ATILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + swz(wc * 64 + j * 32 + fr, 2 * ks + fc));
+                if constexpr (X3) bl[j] = *reinterpret_cast<const bf16x8*>(Bl + swz(wc * 64 + j * 32 + fr, 2 * ks + fc));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(st + swz(wr * 128 + i * 32 + fr, 2 * ks + fc));
+                if constexpr (X3) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(Al + swz(wr * 128 + i * 32 + fr, 2 * ks + fc));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    __syncthreads();                                              // K-step 0 is staged
+    for (int kt = 0; kt < nk; kt += 2) {
+        compute_ws(buf0);
+        __syncthreads();
+        compute_ws(buf1);
+        __syncthreads();
+    }
+    __syncthreads();                                              // all consumers are done reading the staging buffers
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+                     (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
+                     (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
+                     (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int i = t >> 1, j = t & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
+        epilogue_patch(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec);
+    }
+}
+
+template <bool X3, bool SILU>
+static hipError_t launch_ws2(const LinearArgs& a, hipStream_t stream) {
+    constexpr size_t smem = 2 * (X3 ? 2 : 1) * (size_t)(WS_ATILE + BTILE_B);
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_ws_kernel<X3, SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr != hipSuccess) return attr;
+    const int tiles_m = (a.M + WS_TM - 1) / WS_TM, tiles_n = (a.N + TN - 1) / TN;
+    const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
+    if (n_tiles > (1 << 30)) return hipErrorInvalidValue;
+    const int blocks = (int)((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL((linear_ws_kernel<X3, SILU>), dim3(blocks), dim3(512), smem, stream, a, tiles_n, (int)n_tiles);
+    return hipGetLastError();
+}
+
+template <bool X3>
+static hipError_t launch_ws(const LinearArgs& a, hipStream_t stream) {
+    return a.in_act == ACT_SILU ? launch_ws2<X3, true>(a, stream) : launch_ws2<X3, false>(a, stream);
+}
+
 }  // namespace
 
 // Shapes the large-tile kernel takes: bf16 operand modes, K a multiple of 64, 16-byte aligned rows, at least two row tiles.
@@ -335,7 +498,11 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     static const int force_wm = [] { const char* e = getenv("ADX_GEMM_WM"); return e ? atoi(e) : 0; }();     // tuning knob
     // 256-row tiles halve the X traffic per flop; they need enough tiles to cover the chip (256 CUs, one workgroup each)
     const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + TN - 1) / TN);
-    const bool tall = force_wm ? force_wm == 4 : tiles256 >= 512;
+    const bool tall = force_wm ? force_wm >= 4 : tiles256 >= 512;
+    // measured: the wave-specialised form wins for single-pass bf16 (its producers keep up with 16 MFMAs per K-step per
+    // consumer), the symmetric 256-row form for split operands (L2 -> CU staging bandwidth is the limit there either way)
+    if (tall && (force_wm == 8 || (force_wm == 0 && a.prec == PREC_BF16)))
+        return a.prec == PREC_BF16X3 ? launch_ws<true>(a, stream) : launch_ws<false>(a, stream);
     if (a.prec == PREC_BF16X3) return tall ? launch_big<true, 4>(a, stream) : launch_big<true, 2>(a, stream);
     return tall ? launch_big<false, 4>(a, stream) : launch_big<false, 2>(a, stream);
 }
