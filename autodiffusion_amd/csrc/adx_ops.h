@@ -71,7 +71,9 @@ struct AttentionArgs {
     float* state = nullptr; int64_t state_ld = 0; int64_t state_batch_stride = 0;
     const float* key0 = nullptr;
 };
-hipError_t attention(const AttentionArgs& a, hipStream_t stream);
+hipError_t attention(const AttentionArgs& a, hipStream_t stream);         // picks attention_mfma when attention_mfma_ok(a)
+bool attention_mfma_ok(const AttentionArgs& a);                            // Skv <= 128, head dims multiples of 16, no mask
+hipError_t attention_mfma(const AttentionArgs& a, hipStream_t stream);    // attn_mfma.hip
 
 // Attention of a FEW queries (Sq <= 16 per launch group) against many keys, head_dim 4: one workgroup per
 // (batch item, group of NQ queries), all heads; keys are spread over the threads and the per-thread softmax

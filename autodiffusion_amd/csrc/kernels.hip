@@ -792,6 +792,8 @@ hipError_t attention(const AttentionArgs& a, hipStream_t stream) {
         else hipLaunchKernelGGL(attn_small_kernel<16>, grid, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
+    static const bool no_mfma = [] { const char* e = getenv("ADX_ATTN_VALU"); return e && e[0] == '1'; }();   // tuning knob
+    if (!no_mfma && attention_mfma_ok(a)) return attention_mfma(a, stream);
     const size_t smem = sizeof(float) * ((size_t)QT * a.Skv + QT * DC + KC * (DC + 1));
     if (smem > 64 * 1024) return hipErrorInvalidValue;   // Skv <= ~880 for the general kernel
     dim3 grid((a.Sq + QT - 1) / QT, a.H, a.B);
