@@ -96,16 +96,31 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttentionArgs a) {
         f32x4 o[DV_TILES];
 #pragma unroll
         for (int u = 0; u < DV_TILES; ++u) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int g = 0; g < n_k4; g += 4) {          // 16 keys per iteration: one float4 of probabilities per lane
-            const float4 pv = *reinterpret_cast<const float4*>(&Ps[r16 * P_LD + 4 * g + 4 * k4]);
-            const float pj[4] = {pv.x, pv.y, pv.z, pv.w};
+        // two key tiles (32 keys) per iteration: all their V loads are issued before the first MFMA needs one
+#pragma unroll 1
+        for (int g = 0; g < n_k4; g += 8) {
+            float vv[2][4][DV_TILES];
+            float4 pv[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = min(4 * g + 4 * k4 + j, Skv - 1);
-                const float* vrow = Vb + (int64_t)key * a.ldv + c0 + r16;
+            for (int e = 0; e < 2; ++e) {
+                const int ge = min(g + 4 * e, n_k4 - 4);                 // a missing second tile re-reads the first; its p is zeroed
+                pv[e] = *reinterpret_cast<const float4*>(&Ps[r16 * P_LD + 4 * ge + 4 * k4]);
+                if (g + 4 * e >= n_k4) pv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int u = 0; u < DV_TILES; ++u)
-                    if (c0 + 16 * u < a.dv) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(pj[j], vrow[16 * u], o[u], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int key = min(4 * ge + 4 * k4 + j, Skv - 1);
+                    const float* vrow = Vb + (int64_t)key * a.ldv + c0 + r16;
+#pragma unroll
+                    for (int u = 0; u < DV_TILES; ++u) vv[e][j][u] = (c0 + 16 * u < a.dv) ? vrow[16 * u] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float pj[4] = {pv[e].x, pv[e].y, pv[e].z, pv[e].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < DV_TILES; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(pj[j], vv[e][j][u], o[u], 0, 0, 0);
             }
         }
 #pragma unroll

@@ -305,9 +305,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormArgs a) {
     }
 }
 
+// Rows of 256 * NCH floats with 16-byte aligned operands: a lane keeps NCH float4 of the row in registers, so the row is
+// read once and every access is a 16-byte one.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float4* x = reinterpret_cast<const float4*>(a.x + map_row(a.xmap, row) * a.ldx);
+    float4* y = reinterpret_cast<float4*>(a.y + map_row(a.ymap, row) * a.ldy);
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { v[i] = x[lane + 64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    const float inv_d = 1.0f / (256.0f * NCH);
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrt_fast(wave_sum(q) * inv_d + a.eps);
+    const float4* sh = a.shift ? reinterpret_cast<const float4*>(a.shift + (int64_t)row * a.ldm) : nullptr;
+    const float4* sc = a.scale ? reinterpret_cast<const float4*>(a.scale + (int64_t)row * a.ldm) : nullptr;
+    const float4* ga = reinterpret_cast<const float4*>(a.gamma);
+    const float4* be = reinterpret_cast<const float4*>(a.beta);
+    const float4* gt = a.gate ? reinterpret_cast<const float4*>(a.gate + (int64_t)row * a.ldg) : nullptr;
+    const float4* rs = a.res ? reinterpret_cast<const float4*>(a.res + (int64_t)row * a.ldr) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        float o[4] = {v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd};
+        if (ga) { const float4 g = ga[c], b = be[c]; o[0] = fmaf(o[0], g.x, b.x); o[1] = fmaf(o[1], g.y, b.y); o[2] = fmaf(o[2], g.z, b.z); o[3] = fmaf(o[3], g.w, b.w); }
+        if (sc) { const float4 k = sc[c], h = sh[c]; o[0] = fmaf(o[0], 1.f + k.x, h.x); o[1] = fmaf(o[1], 1.f + k.y, h.y); o[2] = fmaf(o[2], 1.f + k.z, h.z); o[3] = fmaf(o[3], 1.f + k.w, h.w); }
+        if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        if (gt) { const float4 g = gt[c]; o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
+        if (rs) { const float4 r = rs[c]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+        y[c] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
     if (a.rows <= 0 || a.d <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
+    const bool vec = (a.d % 256) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && aligned16(a.x) && aligned16(a.y) &&
+                     (!a.gamma || (aligned16(a.gamma) && aligned16(a.beta))) &&
+                     (!a.shift || ((a.ldm & 3) == 0 && aligned16(a.shift) && aligned16(a.scale))) &&
+                     (!a.gate || ((a.ldg & 3) == 0 && aligned16(a.gate))) && (!a.res || ((a.ldr & 3) == 0 && aligned16(a.res)));
+    const dim3 grid((a.rows + 3) / 4), block(256);
+    if (vec) {
+        switch (a.d / 256) {
+            case 1: hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, stream, a); return hipGetLastError();
+            case 2: hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, block, 0, stream, a); return hipGetLastError();
+            case 3: hipLaunchKernelGGL(layernorm_vec_kernel<3>, grid, block, 0, stream, a); return hipGetLastError();
+            case 4: hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, block, 0, stream, a); return hipGetLastError();
+            case 8: hipLaunchKernelGGL(layernorm_vec_kernel<8>, grid, block, 0, stream, a); return hipGetLastError();
+            case 16: hipLaunchKernelGGL(layernorm_vec_kernel<16>, grid, block, 0, stream, a); return hipGetLastError();
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

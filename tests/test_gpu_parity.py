@@ -95,7 +95,7 @@ def test_op_linear_asymmetric_identity(dev):
     assert torch.equal(yb, w.T.contiguous())     # small integers are exact in bf16
 
 
-@pytest.mark.parametrize("d", [32, 64, 96, 256, 1000, 4096])
+@pytest.mark.parametrize("d", [32, 64, 96, 256, 512, 768, 1000, 1024, 2048, 4096])
 def test_op_layernorm(dev, d):
     from autodiffusion_amd import ops
     from oracle import nets
