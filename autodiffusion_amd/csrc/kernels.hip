@@ -558,27 +558,36 @@ __global__ __launch_bounds__(256) void attn_fewq3_kernel(const AttentionArgs a) 
     }
     const float* Kb = a.K + (int64_t)b * a.k_batch_stride + h * DH;
     const float* Vb = a.V + (int64_t)b * a.v_batch_stride + h * DH;
-    // software pipeline: the next key's K/V are in flight while this one is processed
-    float4 kn = make_float4(0.f, 0.f, 0.f, 0.f), vn = kn;
-    if (kl < a.Skv) {
-        kn = *reinterpret_cast<const float4*>(Kb + (int64_t)kl * a.ldk);
-        vn = *reinterpret_cast<const float4*>(Vb + (int64_t)kl * a.ldv);
-    }
-    for (int j = kl; j < a.Skv; j += 8) {
-        const float4 kk = kn, vv = vn;
-        if (j + 8 < a.Skv) {
-            kn = *reinterpret_cast<const float4*>(Kb + (int64_t)(j + 8) * a.ldk);
-            vn = *reinterpret_cast<const float4*>(Vb + (int64_t)(j + 8) * a.ldv);
-        }
+    // software pipeline: DEPTH keys' K/V are in flight per lane while one is processed (keys past the end re-read the
+    // last key with their probability forced to zero by a -inf score)
+    constexpr int DEPTH = 4;
+    float4 kq[DEPTH], vq[DEPTH];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
-            const float mn = fmaxf(m[i], s);
-            const float al = exp2_fast(m[i] - mn), p = exp2_fast(s - mn);
-            l[i] = fmaf(l[i], al, p);
-            o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
-            o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
-            m[i] = mn;
+    for (int u = 0; u < DEPTH; ++u) {
+        const int j = min(kl + 8 * u, a.Skv - 1);
+        kq[u] = *reinterpret_cast<const float4*>(Kb + (int64_t)j * a.ldk);
+        vq[u] = *reinterpret_cast<const float4*>(Vb + (int64_t)j * a.ldv);
+    }
+    for (int j0 = kl; j0 < a.Skv; j0 += 8 * DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int j = j0 + 8 * u;
+            const float4 kk = kq[u], vv = vq[u];
+            const int jn = min(j + 8 * DEPTH, a.Skv - 1);
+            kq[u] = *reinterpret_cast<const float4*>(Kb + (int64_t)jn * a.ldk);
+            vq[u] = *reinterpret_cast<const float4*>(Vb + (int64_t)jn * a.ldv);
+            const bool live = j < a.Skv;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
+                s = live ? s : -INFINITY;
+                const float mn = fmaxf(m[i], s);
+                const float al = exp2_fast(m[i] - mn), p = exp2_fast(s - mn);
+                l[i] = fmaf(l[i], al, p);
+                o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
+                o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
+                m[i] = mn;
+            }
         }
     }
 #pragma unroll
@@ -607,7 +616,8 @@ hipError_t attention_few_queries(const AttentionArgs& a, hipStream_t stream) {
     if (a.B <= 0 || a.Sq <= 0 || a.Skv <= 0 || a.H != 8 || a.dh != 4 || a.dv != 4 || a.mask_off >= 0) return hipErrorInvalidValue;
     if (a.Sq == 1) hipLaunchKernelGGL(attn_fewq_kernel<1>, dim3(1, a.B), dim3(256), 0, stream, a);
     else if (a.Sq <= 4) hipLaunchKernelGGL(attn_fewq_kernel<4>, dim3(1, a.B), dim3(256), 0, stream, a);
-    else if (!a.key0) hipLaunchKernelGGL(attn_fewq3_kernel, dim3((a.Sq + 11) / 12, a.B), dim3(256), 0, stream, a);
+    else if (!a.key0 && a.Skv >= 8)      // every key lane of the pipelined kernel needs at least one real key
+        hipLaunchKernelGGL(attn_fewq3_kernel, dim3((a.Sq + 11) / 12, a.B), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fewq_kernel<12>, dim3((a.Sq + 11) / 12, a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -33,6 +33,13 @@ constexpr int V_LNFG = V_LAYER0 + 4 * VL_SIZE, V_LNFB = V_LNFG + 32, V_HEAD_B = 
 
 struct A8 { f32x4 t[2]; };               // a [16 rows x 32 features] activation in accumulator layout
 
+// LDS accesses of one wavefront execute in program order; this only stops the compiler from moving them across.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // DEPTH-block look-ahead over the weight image (registers; the shifts are moves that issue under the MFMAs).
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void tail_mfma_kernel(const TailMfmaArgs a) {
     for (int i = threadIdx.x; i < V_TOTAL; i += 256) vec[i] = a.vecs[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
-    // every wave runs the whole body (barriers inside); waves past the batch recompute the last item and store nothing
+    // waves past the batch recompute the last item and store nothing
     const int item = blockIdx.x * 4 + wave;
     const bool live = item < a.B;
     const int b = min(item, a.B - 1);
@@ -238,9 +245,9 @@ __global__ __launch_bounds__(256) void tail_mfma_kernel(const TailMfmaArgs a) {
         const A8 qs = mm32(ws, h, bias8(lv + VL_BQKV, q));
         const A8 ks = mm32(ws, h, bias8(lv + VL_BQKV + 32, q));
         const A8 vs = mm32(ws, h, bias8(lv + VL_BQKV + 64, q));
-        __syncthreads();                                 // the previous readers of the tile are done
+        wave_sync();                                     // the K/V tile is private to the wave: order its LDS traffic only
         store_kv(kv, ks, vs, n, q);
-        __syncthreads();
+        wave_sync();
         A8 at = attend(kv, qs, n, q, T, 0);
         y = mm32(ws, at, add8(y, bias8(lv + VL_BO, q)));
         // cross-attention: query i sees memory rows 0..i+1
@@ -248,9 +255,9 @@ __global__ __launch_bounds__(256) void tail_mfma_kernel(const TailMfmaArgs a) {
         const A8 qc = mm32(ws, h, bias8(lv + VL_BQ, q));
         const A8 km = mm32(ws, xm, bias8(lv + VL_BKV, q));
         const A8 vm = mm32(ws, xm, bias8(lv + VL_BKV + 32, q));
-        __syncthreads();
+        wave_sync();
         store_kv(kv, km, vm, n, q);
-        __syncthreads();
+        wave_sync();
         at = attend(kv, qc, n, q, TR, 1);
         y = mm32(ws, at, add8(y, bias8(lv + VL_BO2, q)));
         // feed-forward
