@@ -222,6 +222,16 @@ hipError_t tail_mfma_pack_block(const float* W, int ldw, int row0, int col0, voi
 hipError_t tail_mfma_pack_ends(const float* Win, const float* Whead, void* image, hipStream_t stream);
 hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream);
 
+// Reduce M sampled trajectories per scenario to k modes (farthest-point sampling on the end points + EM); see modes.hip.
+struct SelectModesArgs {
+    const float* traj = nullptr;      // [B][M][L][D]
+    float* modes = nullptr;           // [B][k][L][D], ordered by weight (descending)
+    float* weights = nullptr;         // [B][k]
+    int B = 0, M = 0, L = 0, D = 0, k = 0, em_iter = 25;
+    float org_sigma = 0.1f, init_sigma = 0.1f;
+};
+hipError_t select_modes(const SelectModesArgs& a, hipStream_t stream);
+
 // f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);
 // strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)

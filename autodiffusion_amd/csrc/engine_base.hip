@@ -237,6 +237,15 @@ ADX_API int adx_op_linear(const float* x, const void* w, const float* bias, floa
     return done(linear(a, (hipStream_t)stream), "linear");
 }
 
+ADX_API int adx_op_select_modes(const float* traj, int B, int M, int L, int D, int k, int em_iter, float* modes, float* weights,
+                                void* stream) {
+    if (!traj || !modes || !weights) return fail(ADX_EINVAL, "select_modes: null pointer");
+    if (k <= 0 || k > M) return fail(ADX_EINVAL, "select_modes: k must be in 1..M");
+    SelectModesArgs a;
+    a.traj = traj; a.modes = modes; a.weights = weights; a.B = B; a.M = M; a.L = L; a.D = D; a.k = k; a.em_iter = em_iter;
+    return done(select_modes(a, (hipStream_t)stream), "select_modes");
+}
+
 ADX_API int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
     if (!x || !y) return fail(ADX_EINVAL, "to_bf16: null pointer");
     return done(to_bf16(x, y, nullptr, n, (hipStream_t)stream), "to_bf16");

@@ -271,9 +271,17 @@ class DiffusionDecoder(nn.Module):
         traj, scores = self.model(hidden_output, info_dict=info_dict, batch_size=pred_traj_num, determin=False,
                                   mc_num=self.config.mc_num, noise=noise, return_scores=True)
         if self.config.mc_num > self.k:
-            raise NotImplementedError("reducing mc_num samples to k modes (select_k_from_mc: farthest-point sampling + EM) "
-                                      "is not part of the sampling path; set k = mc_num to get every sample")
+            traj, scores = select_k_from_mc(traj, scores, self.k)
         return traj
+
+
+def select_k_from_mc(traj_logits: torch.Tensor, scores: torch.Tensor, k: int):
+    """Reduce (B, mc_num, S, C) samples to k modes (farthest-point sampling on the end points + 25 EM iterations of a
+    diagonal Gaussian mixture); returns (modes (B, k, S, C), mode weights (B, k)) ordered by weight.  As in the reference
+    (transformer4planning/models/utils.py:120-132; modify_traj_utils.py:183-184 multiplies the scores by zero) the sample
+    scores do not influence the result."""
+    from . import ops
+    return ops.select_modes(traj_logits, k, em_iter=25)
 
 
 def dit_config(n_embd=256, n_layer=4, n_head=8, backbone="DiT", n_inner=None, k=1, mc_num=1, diffusion_timesteps=10,

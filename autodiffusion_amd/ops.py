@@ -110,3 +110,14 @@ def sched_step(x: torch.Tensor, model_out: torch.Tensor, z: Optional[torch.Tenso
     x0 = torch.empty_like(x) if want_x0 else None
     check(lib.adx_op_sched_step(ptr(x), ptr(model_out), ptr(z), ptr(xn), ptr(x0), x.numel(), ptr(coef), current_stream()), "sched_step")
     return (xn, x0) if want_x0 else xn
+
+
+def select_modes(traj: torch.Tensor, k: int, em_iter: int = 25):
+    """(B, M, L, D) sampled trajectories -> (modes (B, k, L, D), weights (B, k)), weights descending."""
+    lib = _lib.load()
+    traj = f32c(traj)
+    B, M, L, D = traj.shape
+    modes = torch.empty(B, k, L, D, device=traj.device, dtype=torch.float32)
+    weights = torch.empty(B, k, device=traj.device, dtype=torch.float32)
+    check(lib.adx_op_select_modes(ptr(traj), B, M, L, D, int(k), int(em_iter), ptr(modes), ptr(weights), current_stream()), "select_modes")
+    return modes, weights

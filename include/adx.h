@@ -61,6 +61,14 @@ int adx_op_linear(const float* x, const void* w, const float* bias, float* y, in
                   int prec, void* stream);
 int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 
+/* select_k_from_mc (models/utils.py:120-132 -> utils/modify_traj_utils.py: farthest_point_sample_PointCloud :8-30,
+ * run_EM_algorithm / _compute_EM_algorithm :124-219): reduce the M sampled trajectories traj[B][M][L][D] of every
+ * scenario to k modes -- farthest-point sampling on the end points starting at sample 0, then em_iter (reference: 25)
+ * EM iterations of a diagonal Gaussian mixture with uniform sample weights; modes[B][k][L][D] ordered by weights[B][k],
+ * descending. */
+int adx_op_select_modes(const float* traj, int B, int M, int L, int D, int k, int em_iter, float* modes, float* weights,
+                        void* stream);
+
 /* LayerNorm over the last axis, optionally affine (gamma/beta), optionally followed by the adaLN
  * `modulate` x*(1+scale)+shift with per-row shift/scale of row stride ld_mod, optionally ReLU.
  * nn.LayerNorm uses in transformer.py:132 and torch TransformerEncoder/DecoderLayer; custom LayerNorm

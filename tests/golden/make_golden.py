@@ -339,6 +339,29 @@ def g10_metrics():
          fde1=err[:, 9], fde3=err[:, 29], fde5=err[:, 49], fde8=err[:, -1])
 
 
+# ----------------------------------------------------------------------------- G11
+def g11_select_modes():
+    """select_k_from_mc (farthest-point sampling on end points + 25 EM iterations), models/utils.py:120-132."""
+    out = {}
+    g = np.random.default_rng(5)
+    for tag, B, mc, k in (("mc16_k6", 3, 16, 6), ("mc40_k3", 2, 40, 3)):
+        t = np.arange(1, 81, dtype=np.float32)[None, None, :, None]
+        centers = g.standard_normal((B, 4, 1, 4)).astype(np.float32) * np.array([0.3, 0.05, 0.0, 0.002], np.float32)
+        which = g.integers(0, 4, size=(B, mc))
+        base = np.take_along_axis(centers, which[:, :, None, None], axis=1)                      # (B, mc, 1, 4)
+        traj = base * t + 1.0 * t * np.array([1.0, 0.0, 0.0, 0.0], np.float32)                   # cluster drift along x
+        traj = traj + g.standard_normal((B, mc, 80, 4)).astype(np.float32) * np.array([0.3, 0.1, 0.0, 0.01], np.float32)
+        traj = torch.from_numpy(traj.astype(np.float32))
+        scores = torch.from_numpy(-g.random((B, mc)).astype(np.float32) * 50.0)                   # the decoder's -sum z^2 scores
+        with torch.no_grad():
+            tk, sk = ref_utils.select_k_from_mc(traj, scores, k)
+        out[f"{tag}_traj"] = traj
+        out[f"{tag}_scores"] = scores
+        out[f"{tag}_traj_k"] = tk
+        out[f"{tag}_scores_k"] = sk
+    save("g11_select_modes", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -350,3 +373,4 @@ if __name__ == "__main__":
     g8_chunk_loop()
     g9_dit_loop()
     g10_metrics()
+    g11_select_modes()

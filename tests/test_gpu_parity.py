@@ -431,3 +431,44 @@ def test_errors(dev):
     w.train()
     with pytest.raises(NotImplementedError):
         w({}, torch.zeros(1, 10, 4))
+
+
+# ------------------------------------------------------------------ multi-modal reduction (select_k_from_mc)
+@pytest.mark.parametrize("tag,k", [("mc16_k6", 6), ("mc40_k3", 3)])
+def test_select_modes(dev, golden, tag, k):
+    from autodiffusion_amd import dit
+    from oracle import modes
+    from test_oracle_golden import canonical_modes
+    g = golden("g11_select_modes")
+    traj = T(g[f"{tag}_traj"])
+    got_t, got_q = dit.select_k_from_mc(traj.to(dev), T(g[f"{tag}_scores"]).to(dev), k)
+    got_t, got_q = canonical_modes(got_t.cpu(), got_q.cpu())
+    ref_t, ref_q = canonical_modes(T(g[f"{tag}_traj_k"]), T(g[f"{tag}_scores_k"]))
+    np.testing.assert_allclose(got_q.numpy(), ref_q.numpy(), atol=1e-5)
+    assert rel_err(got_t, ref_t) < 1e-5
+    # a larger seeded case against the oracle: 64 scenarios, 24 samples, soft assignments (wide clusters)
+    gen = torch.Generator().manual_seed(3)
+    big = torch.cumsum(torch.randn(64, 24, 80, 4, generator=gen) * 0.05, dim=2) + torch.randn(64, 24, 1, 4, generator=gen) * 0.2
+    o_t, o_q = canonical_modes(*modes.select_modes(big, 5))
+    h_t, h_q = dit.select_k_from_mc(big.to(dev), torch.zeros(64, 24).to(dev), 5)
+    h_t, h_q = canonical_modes(h_t.cpu(), h_q.cpu())
+    np.testing.assert_allclose(h_q.numpy(), o_q.numpy(), atol=2e-4)
+    assert rel_err(h_t, o_t) < GATE
+
+
+def test_decoder_generate_k_modes(dev):
+    """DiffusionDecoder.generate with mc_num > k returns (B, k, 80, 4), ordered modes of the mc_num samples."""
+    from autodiffusion_amd import dit, synth
+    cfg = dit.dit_config(64, 2, 4, "DiT", k=3, mc_num=8, diffusion_timesteps=10)
+    dec = dit.DiffusionDecoder(cfg)
+    synth.fill_module_(dec, WSEED)
+    dec = dec.to(dev).eval()
+    state = synth.hidden_state(2, 64, ISEED).to(dev)
+    noise = synth.noise(16, (11,), (80, 4), NSEED).to(dev)
+    out = dec.generate(state, noise=noise)
+    assert out.shape == (2, 3, 80, 4) and bool(torch.isfinite(out).all())
+    allk = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "DiT", k=8, mc_num=8, diffusion_timesteps=10))
+    synth.fill_module_(allk, WSEED)
+    samples = allk.to(dev).eval().generate(state, noise=noise)              # (2, 8, 80, 4): every sample
+    ref, _ = dit.select_k_from_mc(samples, torch.zeros(2, 8, device=dev), 3)
+    assert torch.equal(out, ref)

@@ -290,3 +290,29 @@ def test_diffusers_style_known_answers():
     got = sampling.diffusers_ddpm_step(ac, 10, torch.zeros_like(x), t, x, z)
     var = (1 - a_p) / (1 - a_t) * (1 - al)
     assert torch.allclose(got, mean + var ** 0.5 * z, atol=1e-6)
+
+
+# ------------------------------------------------------------------ G11: multi-modal reduction (select_k_from_mc)
+def canonical_modes(traj, q):
+    """Order modes by (weight descending, end-point x ascending): equal weights leave the reference's order arbitrary."""
+    out_t, out_q = [], []
+    for b in range(traj.shape[0]):
+        key = sorted(range(traj.shape[1]), key=lambda i: (-round(float(q[b, i]), 5), float(traj[b, i, -1, 0])))
+        out_t.append(traj[b, key])
+        out_q.append(q[b, key])
+    return torch.stack(out_t), torch.stack(out_q)
+
+
+@pytest.mark.parametrize("tag,k", [("mc16_k6", 6), ("mc40_k3", 3)])
+def test_select_modes_golden(golden, tag, k):
+    from oracle import modes
+    g = golden("g11_select_modes")
+    traj = T(g[f"{tag}_traj"])
+    got_t, got_q = modes.select_modes(traj, k)
+    ref_t, ref_q = canonical_modes(T(g[f"{tag}_traj_k"]), T(g[f"{tag}_scores_k"]))
+    got_t, got_q = canonical_modes(got_t, got_q)
+    np.testing.assert_allclose(got_q.numpy(), ref_q.numpy(), atol=1e-5)
+    assert rel_err(got_t, ref_t) < 1e-5
+    # farthest-point sampling starts at sample 0 and never repeats a point while distinct ones remain
+    idx = modes.farthest_point_indices(traj[:, :, -1, :], k)
+    assert (idx[:, 0] == 0).all() and all(len(set(r.tolist())) == k for r in idx)
