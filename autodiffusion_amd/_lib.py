@@ -26,7 +26,7 @@ EXPORTS = [
     "adx_op_normalize", "adx_op_denormalize", "adx_op_sched_step",
     "adx_engine_create", "adx_engine_destroy", "adx_engine_set_tensor", "adx_engine_finalize", "adx_engine_reserve",
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
-    "adx_generate_a", "adx_sample_dit", "adx_debug_stage_a", "adx_op_select_modes", "adx_engine_profile", "adx_engine_profile_read",
+    "adx_generate_a", "adx_sample_dit", "adx_debug_stage_a", "adx_op_select_modes", "adx_op_trajectory_metrics", "adx_engine_profile", "adx_engine_profile_read",
 ]
 
 
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
         "adx_sample_dit": ([p, i, p, p, i, p, u, p], i),
         "adx_debug_stage_a": ([p, i, i, i, p], i),
         "adx_engine_profile": ([p, i], i),
+        "adx_op_trajectory_metrics": ([p, p, i, i, i, p, p], i),
         "adx_op_select_modes": ([p, i, i, i, i, i, i, p, p, p], i),
         "adx_engine_profile_read": ([p, i, p, p], i),
     }

@@ -232,6 +232,9 @@ struct SelectModesArgs {
 };
 hipError_t select_modes(const SelectModesArgs& a, hipStream_t stream);
 
+// Per-scenario ADE / FDE / heading errors / max displacement; out[B][18], layout in metrics.hip.  S divides 80, C in {2, 4}.
+hipError_t trajectory_metrics(const float* pred, const float* label, int B, int S, int C, float* out, hipStream_t stream);
+
 // f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);
 // strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)

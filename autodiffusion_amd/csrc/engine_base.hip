@@ -246,6 +246,12 @@ ADX_API int adx_op_select_modes(const float* traj, int B, int M, int L, int D, i
     return done(select_modes(a, (hipStream_t)stream), "select_modes");
 }
 
+ADX_API int adx_op_trajectory_metrics(const float* pred, const float* label, int B, int S, int C, float* out, void* stream) {
+    if (!pred || !label || !out) return fail(ADX_EINVAL, "trajectory_metrics: null pointer");
+    if (S <= 0 || S > 80 || (80 % S) != 0 || (C != 2 && C != 4)) return fail(ADX_EINVAL, "trajectory_metrics: S must divide 80 and C be 2 or 4");
+    return done(trajectory_metrics(pred, label, B, S, C, out, (hipStream_t)stream), "trajectory_metrics");
+}
+
 ADX_API int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
     if (!x || !y) return fail(ADX_EINVAL, "to_bf16: null pointer");
     return done(to_bf16(x, y, nullptr, n, (hipStream_t)stream), "to_bf16");

@@ -66,6 +66,11 @@ int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
  * scenario to k modes -- farthest-point sampling on the end points starting at sample 0, then em_iter (reference: 25)
  * EM iterations of a diagonal Gaussian mixture with uniform sample weights; modes[B][k][L][D] ordered by weights[B][k],
  * descending. */
+/* compute_metrics (trainer.py:184-305), the per-scenario part: out[B][18] = ade at 1/3/5/8 s, fde at 1/3/5/8 s, heading
+ * error of point 0, mean heading error over 3/5/8 s, heading error at points 29/49/79, max displacement over 3/5/8 s
+ * (heading entries are 0 when C == 2).  pred, label: [B][S][C] with S dividing 80 (horizons scale by 80 / S). */
+int adx_op_trajectory_metrics(const float* pred, const float* label, int B, int S, int C, float* out, void* stream);
+
 int adx_op_select_modes(const float* traj, int B, int M, int L, int D, int k, int em_iter, float* modes, float* weights,
                         void* stream);
 

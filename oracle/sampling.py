@@ -253,3 +253,37 @@ def displacement_metrics(pred: np.ndarray, label: np.ndarray) -> Dict[str, np.nd
         "ade1": err[:, :10].mean(1), "ade3": err[:, :30].mean(1), "ade5": err[:, :50].mean(1), "ade8": err[:, :80].mean(1),
         "fde1": err[:, 9], "fde3": err[:, 29], "fde5": err[:, 49], "fde8": err[:, -1],
     }
+
+
+def evaluation_metrics(pred: np.ndarray, label: np.ndarray) -> Dict[str, float]:
+    """Batch means of the evaluation entry (trainer.py:184-305): ADE/FDE horizons, heading errors, scores, miss rates."""
+    S = label.shape[1]
+    rs = int(80 / S) if S < 80 else 1
+    err = np.sqrt((pred[..., 0] - label[..., 0]) ** 2 + (pred[..., 1] - label[..., 1]) ** 2)
+    ade = {n: err[:, :(10 * n if n != 1 else 10) // rs].mean(1) for n in (1, 3, 5, 8)}
+    fde = {1: err[:, 9 // rs], 3: err[:, 29 // rs], 5: err[:, 49 // rs], 8: err[:, -1]}
+    r = {}
+    for n in (1, 3, 5, 8):
+        r[f"ade_horizon{n}_gen"] = ade[n].mean()
+        r[f"fde_horizon{n}_gen"] = fde[n].mean()
+    avg_ade, avg_fde = (ade[3] + ade[5] + ade[8]) / 3, (fde[3] + fde[5] + fde[8]) / 3
+    r["metric_ade"], r["metric_fde"] = avg_ade.mean(), avg_fde.mean()
+    r["ade_score"] = np.maximum(1 - avg_ade / 8, 0).mean()
+    r["fde_score"] = np.maximum(1 - avg_fde / 8, 0).mean()
+    if pred.shape[-1] == 4:
+        wrap = lambda a: np.arctan2(np.sin(a), np.cos(a))
+        he = np.abs(wrap(wrap(pred[..., -1]) - wrap(label[..., -1])))
+        ahe = {n: he[:, :(10 * n) // rs].mean(1) for n in (3, 5, 8)}
+        fhe = {3: he[:, 29 // rs], 5: he[:, 49 // rs], 8: he[:, 79 // rs]}
+        r["ahe_1_gen"] = he[:, 0].mean()
+        for n in (3, 5, 8):
+            r[f"ahe_horizon{n}_gen"] = ahe[n].mean()
+            r[f"fhe_horizon{n}_gen"] = fhe[n].mean()
+        avg_ahe, avg_fhe = (ahe[3] + ahe[5] + ahe[8]) / 3, (fhe[3] + fhe[5] + fhe[8]) / 3
+        r["metric_ahe"], r["metric_fhe"] = avg_ahe.mean(), avg_fhe.mean()
+        r["ahe_score"] = np.maximum(1 - avg_ahe / 0.8, 0).mean()
+        r["fhe_score"] = np.maximum(1 - avg_fhe / 0.8, 0).mean()
+    miss = [(err[:, :(10 * n) // rs].max(1) > th).astype(np.float64) for n, th in ((3, 6), (5, 8), (8, 16))]
+    r["miss_rate3"], r["miss_rate5"], r["miss_rate8"] = (m.mean() for m in miss)
+    r["total_miss_rate"] = ((miss[0] + miss[1] + miss[2]) >= 1).astype(np.float64).mean()
+    return {k: float(v) for k, v in r.items()}

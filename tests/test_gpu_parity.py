@@ -472,3 +472,19 @@ def test_decoder_generate_k_modes(dev):
     samples = allk.to(dev).eval().generate(state, noise=noise)              # (2, 8, 80, 4): every sample
     ref, _ = dit.select_k_from_mc(samples, torch.zeros(2, 8, device=dev), 3)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("S,C", [(80, 4), (8, 4), (80, 2), (40, 4)])
+def test_trajectory_metrics_kernel(dev, S, C):
+    """The fused metrics kernel against the torch formulas and the oracle's restatement of compute_metrics."""
+    from autodiffusion_amd import metrics
+    from oracle import sampling
+    g = torch.Generator().manual_seed(S + C)
+    scale = torch.tensor([9.0, 4.0, 0.0, 2.5][:C])
+    pred, label = torch.randn(1030, S, C, generator=g) * scale, torch.randn(1030, S, C, generator=g) * scale
+    dev_t = metrics.per_scenario(pred.to(dev), label.to(dev)).cpu()
+    np.testing.assert_allclose(dev_t.numpy(), metrics.per_scenario(pred, label).numpy(), rtol=2e-5, atol=2e-5)
+    a = metrics.compute_metrics(pred.to(dev), label.to(dev))
+    b = sampling.evaluation_metrics(pred.double().numpy(), label.double().numpy())
+    for k in b:
+        assert abs(a[k] - b[k]) < 2e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])

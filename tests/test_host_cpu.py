@@ -216,3 +216,22 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_metrics_host_formulas(golden):
+    """metrics.py (torch path) against the golden ADE/FDE vectors and the oracle's restatement of compute_metrics."""
+    from autodiffusion_amd import metrics
+    from oracle import sampling
+    m = golden("g10_metrics")
+    got = metrics.ade_fde(torch.from_numpy(m["pred"]), torch.from_numpy(m["label"]))
+    for k in ("ade1", "ade3", "ade5", "ade8", "fde1", "fde3", "fde5", "fde8"):
+        np.testing.assert_allclose(got[k].numpy(), m[k], rtol=1e-6, atol=1e-6)
+    g = np.random.default_rng(9)
+    for S, C in ((80, 4), (8, 4), (80, 2)):
+        pred = (g.standard_normal((33, S, C)) * np.array([9.0, 4.0, 0.0, 2.5][:C])).astype(np.float32)
+        label = (g.standard_normal((33, S, C)) * np.array([9.0, 4.0, 0.0, 2.5][:C])).astype(np.float32)
+        a = metrics.compute_metrics(torch.from_numpy(pred), torch.from_numpy(label))
+        b = sampling.evaluation_metrics(pred.astype(np.float64), label.astype(np.float64))
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) < 1e-5 * max(1.0, abs(b[k])), (S, C, k, a[k], b[k])
