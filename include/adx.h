@@ -4,7 +4,7 @@
  *
  * The reference implements this path as Python/PyTorch modules; it has no FFI of its own.
  * Each entry point below therefore names the reference *Python* interface it stands in for
- * (paths relative to the reference tree).  A binding is a ctypes stub; see INTEGRATION.md.
+ * (paths relative to the reference tree).  A binding is a ctypes stub (autodiffusion_amd/_lib.py is one).
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller unless its name ends in _host;
