@@ -43,7 +43,7 @@ __device__ __forceinline__ void wave_sync() {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // DEPTH-block look-ahead over the weight image (registers; the shifts are moves that issue under the MFMAs).
-constexpr int DEPTH = 4;
+constexpr int DEPTH = 2;
 struct WStream {
     const float4* p;                     // next block to fetch (already offset by the lane)
     float4 a[DEPTH][BLOCK_SLOTS];
@@ -196,7 +196,7 @@ __device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int n, int q
     return o;
 }
 
-__global__ __launch_bounds__(256) void tail_mfma_kernel(const TailMfmaArgs a) {
+__global__ __launch_bounds__(256, 4) void tail_mfma_kernel(const TailMfmaArgs a) {
     __shared__ __attribute__((aligned(16))) float vec[V_TOTAL];
     __shared__ __attribute__((aligned(16))) float kv_all[4][16 * KV_LD];
     for (int i = threadIdx.x; i < V_TOTAL; i += 256) vec[i] = a.vecs[i];
