@@ -50,6 +50,7 @@ struct EngineA final : adx_engine {
     // per-call map cache: states of the map queries over the map keys (the maps do not change between chunks)
     bool split_cache = false;
     float* STM = nullptr;
+    float* KV1 = nullptr;      // fused path: layer-1 keys | values, [B*L][2d]
     bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
     // elide level 3: the per-row pipeline between the two encoder attentions runs as one fused kernel
     bool fused = false;
@@ -140,6 +141,7 @@ struct EngineA final : adx_engine {
             take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
             take(&ATT0, (size_t)B * std::max<size_t>(steps.size(), 1) * d);
             if (split_cache) take(&STM, BL * H * 6);
+            take(&KV1, BL * 2 * d);
         }
         *bytes = off;
         return ADX_OK;
@@ -393,7 +395,7 @@ struct EngineA final : adx_engine {
         r.x0_time = tx0 + (int64_t)step * d;
         r.key0 = tqkv0 + (int64_t)step * 3 * d + d;
         r.image = rows_image; r.vecs = rows_vecs;
-        r.kv = QKV + d; r.ldkv = 3 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;
+        r.kv = KV1; r.ldkv = 2 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
         return r;
     }
@@ -434,6 +436,13 @@ struct EngineA final : adx_engine {
     }
 
     // ---------------------------------------------------------------------------------- the network
+    // last encoder layer on the fused path: queries of the T+1 visible rows (in QKV) against the compact K | V rows
+    AttentionArgs fused_attn_args(int B) const {
+        AttentionArgs at = enc_attn_args(B, T + 1);
+        at.K = KV1; at.V = KV1 + d; at.ldk = at.ldv = 2 * d; at.k_batch_stride = at.v_batch_stride = (int64_t)L * 2 * d;
+        return at;
+    }
+
     AttentionArgs enc_attn_args(int B, int rq) const {
         const int dh = d / H;
         AttentionArgs at;
@@ -474,7 +483,7 @@ struct EngineA final : adx_engine {
             ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s));
             prof_end(s);
             prof_begin(2, s);
-            ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
+            ADX_HIP(attention_few_queries(fused_attn_args(B), s));
             prof_end(s);
             if (tail_ok && io.x_next && stepped) {
                 prof_begin(3, s);
@@ -589,7 +598,7 @@ struct EngineA final : adx_engine {
             if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
             else if (stage == 1) {
                 ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s));
-            } else if (stage == 2) ADX_HIP(attention_few_queries(enc_attn_args(B, T + 1), s));
+            } else if (stage == 2) ADX_HIP(attention_few_queries(fused_attn_args(B), s));
             else if (stage == 3) {
                 if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
                 ADX_TRY(launch_tail(B, XS0, nullptr, steps_dev, XS1, MOUT, s));
