@@ -7,8 +7,9 @@
 // the weight image stores A fragments with the matching permuted k order, so an activation never leaves the
 // registers between two maps.  In that layout a lane owns two complete attention heads (q and q + 4) of its row, a
 // LayerNorm is 8 registers + two cross-lane adds, and keys/values reach the other rows through a 4 KB LDS tile.
-// Weights are not staged in LDS: the image is laid out in consumption order and streamed from L2 with a four-block
-// register look-ahead (a block = one 32x32 map = 16 MFMAs), so the loads of block i+4 fly under the MFMAs of block i.
+// Weights are not staged in LDS: the image is laid out in consumption order and streamed from L2 with a two-block
+// register look-ahead (a block = one 32x32 map = 16 MFMAs), so the loads of block i+2 fly under the MFMAs of block i;
+// a deeper look-ahead costs the fourth resident wave per SIMD and measured slower.
 // Arithmetic is fp32 throughout (the trajectory path stays fp32 in every precision mode).
 #include "adx_ops.h"
 #include "fastmath.h"
