@@ -537,77 +537,146 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
     }
 }
 
-// Variant for up to 12 queries: wave w owns queries 3w..3w+2 and scans ALL keys (8 heads x 8 key lanes), so a thread
-// holds three softmax states instead of twelve -- four times the resident waves to hide the K/V load latency; the
-// four waves read the same key rows, which the L1/L2 serve after the first touch.
-__global__ __launch_bounds__(256) void attn_fewq3_kernel(const AttentionArgs a) {
-    constexpr int DH = 4, NQ = 3;
+// Variant for up to 12 queries per workgroup.  A lane is (head, query group of 3, key lane); the four waves split the
+// keys, eight per step: wave w takes keys 8s + 2w and 8s + 2w + 1.  The four query groups of a wave read the same
+// K/V addresses, which one load instruction fetches once, so every K/V byte crosses the L2 -> CU path once per
+// workgroup; a thread holds three softmax states, which leaves room for four resident waves per SIMD.  The partial
+// states of the two key lanes merge by shuffle and those of the four waves through LDS.
+//
+// A lane takes its keys four at a time: one running-max update, one rescale of (l, o) and five exponentials per
+// query per block instead of two exponentials and a rescale per key.  One block of K/V is in flight per lane
+// while the other is processed (four resident waves per SIMD cover the rest of the latency).  Keys past the end re-read the last key (its score is a real score, so the running
+// maximum stays valid) and their probabilities are forced to zero.
+namespace {
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+struct FewQ3State {
+    f32x2_t q01, q23;      // scaled query
+    f32x2_t o01, o23;      // running output
+    float m, l;
+};
+
+template <bool MASK>
+__device__ __forceinline__ void fewq3_block(FewQ3State (&st)[3], const float4 (&kk)[4], const float4 (&vv)[4], const bool (&live)[4]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        FewQ3State& t = st[i];
+        float s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x2_t d = t.q01 * f32x2_t{kk[u].x, kk[u].y} + t.q23 * f32x2_t{kk[u].z, kk[u].w};
+            s[u] = d.x + d.y;
+        }
+        const float mn = fmaxf(fmaxf(fmaxf(t.m, s[0]), fmaxf(s[1], s[2])), s[3]);
+        const float al = exp2_fast(t.m - mn);
+        float p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p[u] = exp2_fast(s[u] - mn);
+            if (MASK) p[u] = live[u] ? p[u] : 0.f;
+        }
+        t.l = fmaf(t.l, al, (p[0] + p[1]) + (p[2] + p[3]));
+        f32x2_t o01 = t.o01 * al, o23 = t.o23 * al;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            o01 += f32x2_t{vv[u].x, vv[u].y} * p[u];
+            o23 += f32x2_t{vv[u].z, vv[u].w} * p[u];
+        }
+        t.o01 = o01; t.o23 = o23; t.m = mn;
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 4) void attn_fewq3_kernel(const AttentionArgs a) {
+    constexpr int DH = 4, NQ = 3, KB = 4;
+    __shared__ float red[4][12][8][6];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane & 7, kl = lane >> 3;
-    const int q0 = blockIdx.x * 12 + wave * NQ;
-    float qv[NQ][DH], m[NQ], l[NQ], o[NQ][DH];
+    const int h = lane & 7, qg = (lane >> 3) & 3, kl = 2 * wave + (lane >> 5);      // kl: which of a step's 8 keys
+    const int q0 = blockIdx.x * 12 + qg * NQ;
+    FewQ3State st[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int q = min(q0 + i, a.Sq - 1);
         const float4 t = *reinterpret_cast<const float4*>(a.Q + (int64_t)b * a.q_batch_stride + (int64_t)q * a.ldq + h * DH);
         const float f = a.scale * LOG2E;
-        qv[i][0] = t.x * f; qv[i][1] = t.y * f; qv[i][2] = t.z * f; qv[i][3] = t.w * f;
-        m[i] = -INFINITY; l[i] = 0.f;
-        o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
+        st[i].q01 = f32x2_t{t.x * f, t.y * f}; st[i].q23 = f32x2_t{t.z * f, t.w * f};
+        st[i].o01 = f32x2_t{0.f, 0.f}; st[i].o23 = f32x2_t{0.f, 0.f};
+        st[i].m = -INFINITY; st[i].l = 0.f;
     }
-    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + h * DH;
-    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + h * DH;
-    // software pipeline: DEPTH keys' K/V are in flight per lane while one is processed (keys past the end re-read the
-    // last key with their probability forced to zero by a -inf score)
-    constexpr int DEPTH = 4;
-    float4 kq[DEPTH], vq[DEPTH];
+    // byte offsets of the lane's current key row, advanced by 8 rows per key and clamped to the last row
+    const char* Kb = reinterpret_cast<const char*>(a.K + (int64_t)b * a.k_batch_stride);
+    const char* Vb = reinterpret_cast<const char*>(a.V + (int64_t)b * a.v_batch_stride);
+    const unsigned k_step = 8u * a.ldk * 4u, v_step = 8u * a.ldv * 4u;
+    const unsigned k_last = (unsigned)(a.Skv - 1) * a.ldk * 4u + h * 16u, v_last = (unsigned)(a.Skv - 1) * a.ldv * 4u + h * 16u;
+    unsigned k_off = (unsigned)kl * a.ldk * 4u + h * 16u, v_off = (unsigned)kl * a.ldv * 4u + h * 16u;     // kl < 8 <= Skv
+    float4 kq[2][KB], vq[2][KB];
+    auto fetch = [&](float4 (&kd)[KB], float4 (&vd)[KB]) {
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) {
-        const int j = min(kl + 8 * u, a.Skv - 1);
-        kq[u] = *reinterpret_cast<const float4*>(Kb + (int64_t)j * a.ldk);
-        vq[u] = *reinterpret_cast<const float4*>(Vb + (int64_t)j * a.ldv);
-    }
-    for (int j0 = kl; j0 < a.Skv; j0 += 8 * DEPTH) {
+        for (int u = 0; u < KB; ++u) {
+            kd[u] = *reinterpret_cast<const float4*>(Kb + k_off);
+            vd[u] = *reinterpret_cast<const float4*>(Vb + v_off);
+            k_off = min(k_off + k_step, k_last);
+            v_off = min(v_off + v_step, v_last);
+        }
+    };
+    fetch(kq[0], vq[0]);
+    fetch(kq[1], vq[1]);
+    const int n_full = a.Skv / (8 * KB);                        // blocks in which every lane's four keys exist
+    const bool no_mask[KB] = {true, true, true, true};
+    int t = 0;
+    for (; t + 2 <= n_full; t += 2) {
 #pragma unroll
-        for (int u = 0; u < DEPTH; ++u) {
-            const int j = j0 + 8 * u;
-            const float4 kk = kq[u], vv = vq[u];
-            const int jn = min(j + 8 * DEPTH, a.Skv - 1);
-            kq[u] = *reinterpret_cast<const float4*>(Kb + (int64_t)jn * a.ldk);
-            vq[u] = *reinterpret_cast<const float4*>(Vb + (int64_t)jn * a.ldv);
-            const bool live = j < a.Skv;
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                float s = fmaf(qv[i][0], kk.x, fmaf(qv[i][1], kk.y, fmaf(qv[i][2], kk.z, qv[i][3] * kk.w)));
-                s = live ? s : -INFINITY;
-                const float mn = fmaxf(m[i], s);
-                const float al = exp2_fast(m[i] - mn), p = exp2_fast(s - mn);
-                l[i] = fmaf(l[i], al, p);
-                o[i][0] = fmaf(o[i][0], al, p * vv.x); o[i][1] = fmaf(o[i][1], al, p * vv.y);
-                o[i][2] = fmaf(o[i][2], al, p * vv.z); o[i][3] = fmaf(o[i][3], al, p * vv.w);
-                m[i] = mn;
-            }
+        for (int e = 0; e < 2; ++e) {
+            fewq3_block<false>(st, kq[e], vq[e], no_mask);
+            fetch(kq[e], vq[e]);                                // lands while the other buffer is processed
         }
     }
+    // at most two more blocks: a full one and/or the ragged last one
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = kl + 8 * KB * (t + e);
+        if (8 * KB * (t + e) < a.Skv) {                         // wave-uniform
+            const bool live[KB] = {j < a.Skv, j + 8 < a.Skv, j + 16 < a.Skv, j + 24 < a.Skv};
+            fewq3_block<true>(st, kq[e], vq[e], live);
+        }
+    }
+    // merge the two key lanes of the wave, then the four waves
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            const float m2 = __shfl_xor(m[i], off, 64), l2 = __shfl_xor(l[i], off, 64);
-            const float o0 = __shfl_xor(o[i][0], off, 64), o1 = __shfl_xor(o[i][1], off, 64);
-            const float o2 = __shfl_xor(o[i][2], off, 64), o3 = __shfl_xor(o[i][3], off, 64);
-            const float mn = fmaxf(m[i], m2);
-            const float a1 = mn == -INFINITY ? 0.f : exp2_fast(m[i] - mn), a2 = mn == -INFINITY ? 0.f : exp2_fast(m2 - mn);
-            l[i] = l[i] * a1 + l2 * a2;
-            o[i][0] = o[i][0] * a1 + o0 * a2; o[i][1] = o[i][1] * a1 + o1 * a2;
-            o[i][2] = o[i][2] * a1 + o2 * a2; o[i][3] = o[i][3] * a1 + o3 * a2;
-            m[i] = mn;
+        float m = st[i].m, l = st[i].l, o0 = st[i].o01.x, o1 = st[i].o01.y, o2 = st[i].o23.x, o3 = st[i].o23.y;
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        const float p0 = __shfl_xor(o0, 32, 64), p1 = __shfl_xor(o1, 32, 64);
+        const float p2 = __shfl_xor(o2, 32, 64), p3 = __shfl_xor(o3, 32, 64);
+        const float mn = fmaxf(m, m2);                          // finite: key lane 0 or 1 of wave 0.. saw a real key; -inf only if both empty
+        const float a1 = mn == -INFINITY ? 0.f : exp2_fast(m - mn), a2 = mn == -INFINITY ? 0.f : exp2_fast(m2 - mn);
+        if (lane < 32) {
+            float* r = red[wave][qg * NQ + i][h];
+            r[0] = mn; r[1] = l * a1 + l2 * a2;
+            r[2] = o0 * a1 + p0 * a2; r[3] = o1 * a1 + p1 * a2; r[4] = o2 * a1 + p2 * a2; r[5] = o3 * a1 + p3 * a2;
         }
-        if (lane < 8 && q0 + i < a.Sq) {
-            const float inv = rcp_fast(l[i]);
-            float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)(q0 + i) * a.ldo + lane * DH;
-            *reinterpret_cast<float4*>(Op) = make_float4(o[i][0] * inv, o[i][1] * inv, o[i][2] * inv, o[i][3] * inv);
+    }
+    __syncthreads();
+    if (tid < 96) {
+        const int i = tid >> 3, hh = tid & 7, q = blockIdx.x * 12 + i;
+        if (q < a.Sq) {
+            float mn = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) mn = fmaxf(mn, red[w][i][hh][0]);
+            float ls = 0.f, os[DH] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float* r = red[w][i][hh];
+                const float al = r[0] == -INFINITY ? 0.f : exp2_fast(r[0] - mn);
+                ls += r[1] * al;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) os[c] += r[2 + c] * al;
+            }
+            const float inv = rcp_fast(ls);
+            float* Op = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + hh * DH;
+            *reinterpret_cast<float4*>(Op) = make_float4(os[0] * inv, os[1] * inv, os[2] * inv, os[3] * inv);
         }
     }
 }
