@@ -19,7 +19,7 @@
 //
 // Rows r < n_keep of every batch item (the ones the decoder can see) also get the layer-1 query projection.
 //
-// HBM traffic per row and step (f32): read x0 128 B, q 128 B, softmax state 192 B; write k/v 256 B  -> 704 B.
+// HBM traffic per row and step (f32): read x0 128 B, q 128 B, softmax state 160 B; write k/v 256 B  -> 672 B.
 #include "adx_ops.h"
 #include "fastmath.h"
 
@@ -120,14 +120,23 @@ __device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, con
     return acc;
 }
 
-// GELU(v) = v Phi(v) with erfc(|x|), x = v / sqrt(2), from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7):
-// erfc(|x|) = t (a1 + t (a2 + ...)) exp(-x^2), t = 1 / (1 + p |x|);  v Phi(v) = v - v erfc/2 for v > 0, v erfc/2 otherwise.
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float ax = fabsf(v) * 0.70710678118654752f;
-    const float t = rcp_fast(fmaf(0.3275911f, ax, 1.0f));
-    const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float hr = 0.5f * v * p * exp2_fast(-LOG2E_F * ax * ax);
-    return v > 0.f ? v - hr : hr;
+// GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), with Phi(-t) = 2^q(t) and q a degree-6 polynomial fitted to
+// log2 Phi(-t) on [0, 5.6] (weighted minimax for the error of the product; beyond 5.6 the term is below 1e-7 and t is
+// clamped).  |error| <= 3e-7 over the whole line, with one transcendental and no division: the exponential and the
+// reciprocal of the erfc formulas are quarter-rate instructions and this kernel is bound by vector issue.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per call: the polynomial runs on packed fp32 FMAs
+    const f32x2 av = __builtin_elementwise_abs(v);
+    const f32x2 t = __builtin_elementwise_min(av, f32x2{5.6f, 5.6f});
+    f32x2 q = t * 3.309289604658261e-05f + -0.0007692204089835286f;
+    q = t * q + 0.008080719038844109f;
+    q = t * q + -0.05341210588812828f;
+    q = t * q + -0.4587709605693817f;
+    q = t * q + -1.1512017250061035f;
+    q = t * q + -0.999993085861206f;
+    const f32x2 e = {exp2_fast(q.x), exp2_fast(q.y)};
+    return __builtin_elementwise_max(v, f32x2{0.f, 0.f}) - av * e;
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -166,13 +175,18 @@ __device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gam
 struct RowIn {
     float4 x[4];      // x0 features 8g + 4h .. +3
     float4 q[4];      // layer-0 query of heads 2g + h
-    float4 st[6];     // softmax states of heads 2g + h: 4 x {m, l, o0..o3}, contiguous
+    float4 st[5];     // normalised softmax states of heads 2g + h: 4 x {c, o0..o3}, contiguous (see pack_rows_kernel)
 };
-constexpr int PACK_VECS = 14;   // float4 per lane per 32-row tile: exactly the 448 B a row contributes
+constexpr int PACK_VECS = 13;   // float4 per lane per 32-row tile: exactly the 416 B a row contributes
 
 // The step-independent inputs of a tile are re-read on every diffusion step, so they are stored once per chunk in the
-// order the lanes consume them: packed[(tile * 14 + j) * 64 + lane].  Every load instruction of the row kernel then
+// order the lanes consume them: packed[(tile * 13 + j) * 64 + lane].  Every load instruction of the row kernel then
 // covers 1 KB of contiguous memory (eight full 128-B lines) instead of 32 B out of each of 32 lines.
+// The cached softmax state {m, l, o[4]} of a head (scores in the log2 domain) is stored normalised, as
+// {c = m + log2 l, o / l}: folding one more key (score s, value v) into it is then
+//     out = o/l + g (v - o/l),   g = 1 / (1 + 2^(c - s)),
+// which needs five floats instead of six and one exponential instead of two, and cannot overflow to NaN
+// (2^(c - s) = inf gives g = 0).
 __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, float4* __restrict__ packed, int64_t n_tiles) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_tiles * PACK_VECS * 64) return;
@@ -184,7 +198,17 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, flo
     float4 v;
     if (j < 4) v = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * j);
     else if (j < 8) v = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * (j - 4));
-    else v = *reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24 + 4 * (j - 8));
+    else {
+        const float* st = a.state + row * (NH * 6) + h * 24;
+        float e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f = 4 * (j - 8) + t, g = f / 5, k = f % 5;
+            const float m = st[6 * g], l = st[6 * g + 1];
+            e[t] = k == 0 ? m + log2f(l) : st[6 * g + 1 + k] / l;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+    }
     packed[i] = v;
 }
 
@@ -194,11 +218,14 @@ __device__ __forceinline__ void load_row(RowIn& in, const float4* __restrict__ p
 #pragma unroll
     for (int g = 0; g < 4; ++g) in.q[g] = p[64 * (4 + g)];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) in.st[i] = p[64 * (8 + i)];
+    for (int i = 0; i < 5; ++i) in.st[i] = p[64 * (8 + i)];
 }
 
+// WAVES = resident wavefronts per SIMD the register budget is set for; a workgroup has 4 waves (WAVES <= 3, three
+// workgroups per CU) or 8 waves (WAVES = 4, two workgroups per CU), so that the LDS copies of the weight image fit.
 template <int PREC, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
+__global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
+    constexpr int NT = WAVES == 4 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* img = smem;                                                  // 49152 B
     float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats, then k0 (scaled) and v0
@@ -206,24 +233,28 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
     {
         const uint4* src = reinterpret_cast<const uint4*>(PREC == PREC_F32 ? (const void*)a.img_f32 : (const void*)a.img_bf);
         uint4* dst = reinterpret_cast<uint4*>(img);
-        for (int i = threadIdx.x; i < IMG_F32_FLOATS / 4; i += 256) dst[i] = src[i];
-        for (int i = threadIdx.x; i < VEC_FLOATS; i += 256) vec[i] = a.vecs[i];
+        for (int i = threadIdx.x; i < IMG_F32_FLOATS / 4; i += NT) dst[i] = src[i];
+        for (int i = threadIdx.x; i < VEC_FLOATS; i += NT) vec[i] = a.vecs[i];
         if (threadIdx.x < 64) vec[VEC_FLOATS + threadIdx.x] = a.key0[threadIdx.x] * (threadIdx.x < 32 ? sc : 1.0f);
     }
     __syncthreads();
     const float *bo = vec, *g2 = vec + 32, *be2 = vec + 64, *b2 = vec + 96, *g1 = vec + 128, *be1 = vec + 160, *b1 = vec + 192,
                 *bkv = vec + 320, *bq = vec + 384, *k0s = vec + VEC_FLOATS, *v0s = vec + VEC_FLOATS + 32;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int wave_global = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (NT / 64);
     const int64_t n_rows = (int64_t)a.B * a.L;
 
+    // The inputs of a wave's next tile are requested while the current tile is in its last phase (layer-1 LayerNorm and
+    // projections), where few registers are live: the loads are in flight during a quarter of the tile time instead of
+    // only while the wave waits for them, which is what keeps enough bytes in flight to use the HBM.
+    const int64_t last_tile = (n_rows - 1) >> 5;
+    RowIn in;
+    load_row(in, a.packed + min((int64_t)wave_global, last_tile) * (PACK_VECS * 64) + lane);
     for (int64_t tile0 = (int64_t)wave_global * 32; tile0 < n_rows; tile0 += (int64_t)n_waves * 32) {
         asm volatile("" ::: "memory");      // keep the per-lane bias / LayerNorm vectors in LDS: hoisting them costs ~100 registers
         const int64_t row = min(tile0 + c, n_rows - 1);          // clamp: out-of-range lanes recompute the last row, never store
         const bool live = tile0 + c < n_rows;
         const int r = (int)((unsigned)row % (unsigned)a.L);      // B * L < 2^31 is checked by the launcher
-        RowIn in;
-        load_row(in, a.packed + (tile0 >> 5) * (PACK_VECS * 64) + lane);
         // ---- attention output of layer 0 in accumulator layout: register 4g+i <-> feature 8g + 4h + i
         f32x16 att;
         if (r == 0) {                                           // the time token: inputs change every step
@@ -241,15 +272,13 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
                 const float4 q = in.q[g];
                 const float4 kk = *reinterpret_cast<const float4*>(k0s + 8 * g + 4 * h);
                 const float4 vv = *reinterpret_cast<const float4*>(v0s + 8 * g + 4 * h);
-                const float m0 = stf[6 * g], l0 = stf[6 * g + 1];
                 const float s = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
-                const float mn = fmaxf(m0, s);
-                const float al = exp2_fast(m0 - mn), p = exp2_fast(s - mn);
-                const float inv = rcp_fast(fmaf(l0, al, p));
-                att[4 * g + 0] = fmaf(stf[6 * g + 2], al, p * vv.x) * inv;
-                att[4 * g + 1] = fmaf(stf[6 * g + 3], al, p * vv.y) * inv;
-                att[4 * g + 2] = fmaf(stf[6 * g + 4], al, p * vv.z) * inv;
-                att[4 * g + 3] = fmaf(stf[6 * g + 5], al, p * vv.w) * inv;
+                const float gate = rcp_fast(1.0f + exp2_fast(stf[5 * g] - s));
+                const float o0 = stf[5 * g + 1], o1 = stf[5 * g + 2], o2 = stf[5 * g + 3], o3 = stf[5 * g + 4];
+                att[4 * g + 0] = fmaf(gate, vv.x - o0, o0);
+                att[4 * g + 1] = fmaf(gate, vv.y - o1, o1);
+                att[4 * g + 2] = fmaf(gate, vv.z - o2, o2);
+                att[4 * g + 3] = fmaf(gate, vv.w - o3, o3);
             }
         }
         // ---- y1 = x0 + Wo att + bo
@@ -269,8 +298,9 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 b = *reinterpret_cast<const float4*>(b1 + 32 * nt + 8 * g + 4 * h);
-                f[4 * g + 0] = gelu_erf(f[4 * g + 0] + b.x); f[4 * g + 1] = gelu_erf(f[4 * g + 1] + b.y);
-                f[4 * g + 2] = gelu_erf(f[4 * g + 2] + b.z); f[4 * g + 3] = gelu_erf(f[4 * g + 3] + b.w);
+                const f32x2 lo = gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
+                const f32x2 hi = gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
+                f[4 * g + 0] = lo.x; f[4 * g + 1] = lo.y; f[4 * g + 2] = hi.x; f[4 * g + 3] = hi.y;
             }
             acc2 = mm<PREC>(img, tile_base(2) + nt, f, acc2, lane);
         }
@@ -281,6 +311,9 @@ __global__ __launch_bounds__(256, WAVES) void enc_rows_kernel(const EncRowsArgs 
             y2[4 * g + 0] = y1[4 * g + 0] + acc2[4 * g + 0] + b.x; y2[4 * g + 1] = y1[4 * g + 1] + acc2[4 * g + 1] + b.y;
             y2[4 * g + 2] = y1[4 * g + 2] + acc2[4 * g + 2] + b.z; y2[4 * g + 3] = y1[4 * g + 3] + acc2[4 * g + 3] + b.w;
         }
+        // ---- next tile's inputs (clamped: a wave's last iteration re-reads the last tile and drops it)
+        asm volatile("" ::: "memory");
+        load_row(in, a.packed + min((tile0 >> 5) + n_waves, last_tile) * (PACK_VECS * 64) + lane);
         // ---- layer 1: LayerNorm, K/V projection
         const f32x16 gn = layer_norm32(y2, g1, be1, h);
         const bool keep = live && r < a.n_keep;     // rows the decoder can see: they also need the layer-1 residual and query
@@ -344,14 +377,16 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
     const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 64) * 4;
     const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32;
-    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 3; }();   // tuning knob (2 or 3 resident waves per SIMD)
-    int blocks = (int)((tiles + 3) / 4);
+    static const int waves = [] { const char* e = getenv("ADX_ENC_ROWS_WAVES"); return e ? atoi(e) : 3; }();   // tuning knob (2, 3 or 4 resident waves per SIMD)
+    const int wpb = waves == 4 ? 8 : 4;                 // waves per workgroup
+    int blocks = (int)((tiles + wpb - 1) / wpb);
     const int cap = 256 * (waves == 3 ? 3 : 2);        // resident workgroups; waves stride over the remaining tiles
     if (blocks > cap) blocks = cap;
-#define ADX_LAUNCH_ROWS(P)                                                                                     \
-    do {                                                                                                       \
-        if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3>), dim3(blocks), dim3(256), smem, stream, a); \
-        else hipLaunchKernelGGL((enc_rows_kernel<P, 2>), dim3(blocks), dim3(256), smem, stream, a);            \
+#define ADX_LAUNCH_ROWS(P)                                                                                          \
+    do {                                                                                                            \
+        if (waves == 4) hipLaunchKernelGGL((enc_rows_kernel<P, 4>), dim3(blocks), dim3(512), smem, stream, a);      \
+        else if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3>), dim3(blocks), dim3(256), smem, stream, a); \
+        else hipLaunchKernelGGL((enc_rows_kernel<P, 2>), dim3(blocks), dim3(256), smem, stream, a);                 \
     } while (0)
     if (prec == PREC_F32) ADX_LAUNCH_ROWS(PREC_F32);
     else if (prec == PREC_BF16) ADX_LAUNCH_ROWS(PREC_BF16);

@@ -69,13 +69,13 @@ def time_kernel(fn, iters=20):
 # --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
 # the per-row figure scales with B.  Source: profiles/r01_pmc_enc_rows.txt.
 ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (2906131 * 128 + 3360201 * 64) / (1024 * L_COND)
-ENC_ROWS_ALGO_BYTES_PER_ROW = 448 + 256      # read x0 (128) + layer-0 query (128) + softmax state (192); write layer-1 K, V (256)
+ENC_ROWS_ALGO_BYTES_PER_ROW = 416 + 256      # read x0 (128) + layer-0 query (128) + normalised softmax state (160); write layer-1 K, V (256)
 
 
 def roofline(da, B, step):
     """Dominant kernel of a denoiser call: the fused encoder row pipeline (enc_rows_kernel), one launch per call.
 
-    It streams every conditioning row once -- 704 algorithmic bytes per row, B * 809 rows per launch -- and does
+    It streams every conditioning row once -- 672 algorithmic bytes per row, B * 809 rows per launch -- and does
     22.5 kflop per row on the matrix cores, so HBM bandwidth is the roof that binds (73 us at 8 TB/s against 7.5 us
     at the dense bf16 MFMA peak).  Its launches are timed inside one more pass of the workload: the engine brackets
     every marked launch with events on the launch stream (no graph capture during that pass).  ``stages_us`` lists the
