@@ -67,7 +67,7 @@ def time_kernel(fn, iters=20):
 
 # HBM bytes of one launch of the encoder row kernel at B = 1024 from the L2 fabric-request counters (separate rocprofv3
 # --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
-# the per-row figure scales with B.  Source: profiles/r01_pmc_enc_rows.txt.
+# the per-row figure scales with B.  Source: profiles/r01_pmc_refiner.txt.
 ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (2698261 * 128 + 3387803 * 64) / (1024 * L_COND)
 ENC_ROWS_ALGO_BYTES_PER_ROW = 416 + 256      # read x0 (128) + layer-0 query (128) + normalised softmax state (160); write layer-1 K, V (256)
 
