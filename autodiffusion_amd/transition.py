@@ -1,0 +1,152 @@
+"""Latent-carrying refiner: ``DiffusionTransitionModel`` + the ``StrDiffDiT`` wrapper.  BEST EFFORT, parity unpinned.
+
+Mirrors transformer4planning/models/diffusion_loss/diffusion_transition.py:11-93 and the chunk loop of
+transformer4planning/models/backbone/StrDiffDiT.py:157-235: per chunk of ``frame_stack`` points the sample starts
+from the chunk's prior (not from noise), a diffusers-style DDPM loop calls the denoiser, whose output is a latent
+``z (B, fs, z_dim)`` that ``x_from_z`` projects to the 4-channel model output; the latent of the last step is carried
+to the next chunk; the prior enters with its first frame zeroed and un-normalised; ``data_mean / data_std`` is applied
+to the re-assembled trajectory only.
+
+The reference imports the denoiser of this variant (``TransformerForDiffusion``, called as
+``model(x, t, z, cond, prior)``) from a module that does not define it, so how ``z`` enters the network cannot be
+recovered.  Here ``z`` takes the transition slot of the encoder/decoder ``Transformer`` (whose embedding of that slot
+is named ``prior_z_emb``) through one extra Linear ``z_emb (z_dim -> prior_dim)``; everything else is the reference's
+``Transformer`` with ``output_dim = z_dim``.  The scheduler follows the public DDPMScheduler semantics
+(``schedules.diffusers_rows``).  Every product runs in the HIP library; the step loop is host-side.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib, ops, schedules
+from .refiner import Transformer, _Lin
+
+
+class DiffusionTransitionModel(nn.Module):
+    """cfg needs: x_shape (4,), z_shape (fs, z_dim), frame_stack, n_maps_token, cond_dim, prior_dim and ``scheduler``
+    (num_train_timesteps, beta_start, beta_end, beta_schedule, clip_sample, prediction_type, num_inference_steps)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        z_dim = cfg.z_shape[-1]
+        self.diffusion = Transformer(
+            input_dim=cfg.x_shape[-1], output_dim=z_dim, horizon=cfg.frame_stack, n_cond_steps=cfg.n_maps_token,
+            cond_dim=cfg.cond_dim, n_prior_steps=cfg.frame_stack, prior_dim=cfg.prior_dim, causal_attn=True,
+            precision=getattr(cfg, "precision", "fp32"), elide=min(int(getattr(cfg, "elide", 2)), 2))
+        self.z_emb = _Lin(z_dim, cfg.prior_dim)
+        self.x_from_z = _Lin(cfg.z_shape[1], cfg.x_shape[0])
+        if cfg.scheduler.prediction_type != "epsilon":
+            raise ValueError(f"Unsupported prediction type {cfg.scheduler.prediction_type}")
+
+    def schedule_rows(self):
+        sc = self.cfg.scheduler
+        betas = schedules.diffusers_betas(sc.beta_schedule, sc.num_train_timesteps, sc.beta_start, sc.beta_end)
+        return schedules.diffusers_rows(betas, sc.num_inference_steps, "ddpm", clip_sample=bool(sc.clip_sample))
+
+    def make_noise(self, batch: int, device, n_chunks: Optional[int] = None):
+        n = schedules.n_noise_draws(self.schedule_rows())
+        lead = (n,) if n_chunks is None else (n_chunks, n)
+        return torch.randn(*lead, batch, self.cfg.frame_stack, self.cfg.x_shape[-1], device=device)
+
+    @torch.no_grad()
+    def generate(self, xs, z, cond, prior, noise: Optional[torch.Tensor] = None):
+        """xs (B, fs, 4) [shape only], z (B, fs, z_dim), cond = maps_info (B, 788, cond_dim), prior (B, fs, 4)
+        -> (z_next (B, fs, z_dim), x_next (B, fs, 4)).  ``noise``: (draws, B, fs, 4), default fresh N(0, 1)."""
+        rows = self.schedule_rows()
+        B = prior.shape[0]
+        prior = _lib.f32c(prior)
+        if noise is None:
+            noise = self.make_noise(B, prior.device)
+        transition = ops.linear(_lib.f32c(z), self.z_emb.weight, self.z_emb.bias)
+        condition = dict(maps_info=_lib.f32c(cond), transition_info=transition, trajectory_prior=prior)
+        trajectory = prior.clone()
+        z_output = None
+        for row in rows:
+            t = torch.full((B,), int(row[0]), dtype=torch.long, device=prior.device)
+            z_output = self.diffusion(trajectory, t, condition)
+            model_output = ops.linear(z_output, self.x_from_z.weight, self.x_from_z.bias)
+            zi = int(row[11])
+            trajectory = ops.sched_step(trajectory, model_output, noise[zi] if zi >= 0 else None, row)
+        return z_output, trajectory
+
+    def forward(self, z, x, cond, prior):
+        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
+
+
+class StrDiffDiT(nn.Module):
+    """The refiner half of the reference's ``StrDiffDiT`` wrapper (phase 1, the STR backbone, is passed in as
+    ``str_model`` or bypassed with ``generate(trajectory_prior=..., maps_info=...)``)."""
+
+    def __init__(self, cfg, str_model=None):
+        super().__init__()
+        self.cfg = cfg
+        self.frame_stack = cfg.frame_stack
+        self.x_shape = tuple(cfg.x_shape)
+        self.z_shape = tuple(cfg.z_shape)
+        self.map_cond = cfg.map_cond
+        self.learnable_init_z = cfg.learnable_init_z
+        self.str_model = [str_model]
+        self.transition_model = DiffusionTransitionModel(cfg)
+        self.register_data_mean_std(cfg.data_mean, cfg.data_std)
+        if self.learnable_init_z:
+            self.init_z = nn.Parameter(torch.randn(list(cfg.z_shape)))
+
+    def register_data_mean_std(self, mean: Sequence[float], std: Sequence[float], namespace: str = "data"):
+        self.register_buffer(f"{namespace}_mean", torch.as_tensor(mean, dtype=torch.float32))
+        self.register_buffer(f"{namespace}_std", torch.as_tensor(std, dtype=torch.float32))
+
+    def _unnormalize_x(self, xs):
+        return xs * self.data_std.to(xs.device) + self.data_mean.to(xs.device)
+
+    @torch.no_grad()
+    def generate(self, noise: Optional[torch.Tensor] = None, **kwargs):
+        """-> {"traj_logits": (B, 80, 4) float32}.  ``noise``: (n_chunks, draws, B, fs, 4)."""
+        if "trajectory_prior" in kwargs and "maps_info" in kwargs:
+            trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
+        else:
+            if self.str_model[0] is None:
+                raise ValueError("generate() needs either trajectory_prior/maps_info or a str_model for phase 1")
+            str_result = self.str_model[0].generate(**kwargs)
+            trajectory_prior, maps_info = str_result["traj_logits"], str_result["maps_info"]
+        B, S, C = trajectory_prior.shape
+        if S % self.frame_stack != 0:
+            raise ValueError("Number of frames must be divisible by frame stack size")
+        if getattr(self.cfg, "context_frames", 0) % self.frame_stack != 0:
+            raise ValueError("Number of context frames must be divisible by frame stack size")
+        n_chunks = S // self.frame_stack
+        conditions = _lib.f32c(trajectory_prior).clone()
+        conditions[:, :1] = 0.0                                       # StrDiffDiT.py:182
+        conditions = conditions.reshape(B, n_chunks, self.frame_stack, C)
+        if noise is None:
+            noise = self.transition_model.make_noise(B, conditions.device, n_chunks)
+        if self.learnable_init_z:
+            z = self.init_z[None].expand(B, *self.z_shape).contiguous()
+        else:
+            z = torch.zeros(B, *self.z_shape, device=conditions.device)
+        xs = torch.empty(B, self.frame_stack, C, device=conditions.device)      # shape only
+        preds = []
+        for c in range(n_chunks):
+            z, x_next = self.transition_model.generate(xs, z, maps_info, conditions[:, c].contiguous(), noise=noise[c])
+            preds.append(x_next)
+        out = torch.stack(preds, dim=1).reshape(B, S, C)
+        return {"traj_logits": self._unnormalize_x(out).to(torch.float32)}
+
+    def forward(self, return_dict=None, **kwargs):
+        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path; use generate()")
+
+
+def transition_config(frame_stack: int = 10, z_dim: int = 768, num_train_timesteps: int = 100, num_inference_steps: int = 10,
+                      beta_schedule: str = "squaredcos_cap_v2", learnable_init_z: bool = True,
+                      data_mean=(30.0, 10.0, 0.0, 0.0), data_std=(100.0, 20.0, 1.0, 1.0), precision: str = "fp32") -> SimpleNamespace:
+    """Config with the fields of config/strDiffDiT.yaml that the sampling path reads."""
+    scheduler = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=0.0001, beta_end=0.02,
+                                beta_schedule=beta_schedule, variance_type="fixed_small", clip_sample=True,
+                                prediction_type="epsilon", num_inference_steps=num_inference_steps)
+    return SimpleNamespace(frame_stack=frame_stack, x_shape=(4,), z_shape=(frame_stack, z_dim), n_maps_token=788, cond_dim=256,
+                           prior_dim=4, map_cond=True, learnable_init_z=learnable_init_z, context_frames=0, scheduler=scheduler,
+                           data_mean=list(data_mean), data_std=list(data_std), precision=precision)

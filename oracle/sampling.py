@@ -245,6 +245,44 @@ def explicit_generate(denoise_flat: Callable, ac: np.ndarray, n_infer: int, prio
     return out * std + mean
 
 
+def transition_generate(denoise_z: Callable, z_emb: Callable, x_from_z: Callable, ac: np.ndarray, n_infer: int, prior_full, init_z,
+                        noise, frame_stack: int, data_mean, data_std) -> torch.Tensor:
+    """Latent-carrying wrapper (StrDiffDiT.generate, StrDiffDiT.py:202-235, with DiffusionTransitionModel.
+    conditional_sample, diffusion_transition.py:43-78).  BEST EFFORT, parity unpinned: the reference's denoiser for
+    this variant is missing from its tree; here z enters through ``z_emb`` into the transition slot.
+
+    ``denoise_z(x(B,fs,4), t, transition(B,fs,Cp), prior(B,fs,4)) -> z (B,fs,z_dim)``; ``noise`` is
+    (n_chunks, draws, B, fs, 4), one draw per step with t > 0.  The sample starts from the chunk's prior
+    (diffusion_transition.py:58); the prior's first frame is zeroed (StrDiffDiT.py:182).
+    """
+    B, S, C = prior_full.shape
+    n_chunks = S // frame_stack
+    cond = prior_full.clone()
+    cond[:, :1] = 0.0
+    cond = cond.reshape(B, n_chunks, frame_stack, C)
+    z = init_z[None].expand(B, *init_z.shape)
+    preds = []
+    for c in range(n_chunks):
+        pri = cond[:, c]
+        x = pri.clone()
+        tran = z_emb(z)
+        k = 0
+        for t in diffusers_timesteps(len(ac), n_infer):
+            z_out = denoise_z(x, t, tran, pri)
+            eps = x_from_z(z_out)
+            zz = None
+            if t > 0:
+                zz = noise[c, k]
+                k += 1
+            x = diffusers_ddpm_step(ac, n_infer, eps, t, x, zz)
+        z = z_out
+        preds.append(x)
+    out = torch.stack(preds, dim=1).reshape(B, S, C)
+    mean = torch.as_tensor(data_mean, dtype=torch.float32)
+    std = torch.as_tensor(data_std, dtype=torch.float32)
+    return out * std + mean
+
+
 # ------------------------------------------------------------------ metrics
 def displacement_metrics(pred: np.ndarray, label: np.ndarray) -> Dict[str, np.ndarray]:
     """ADE/FDE at 1/3/5/8 s per scenario (trainer.py:184-234): L2 over (x, y) per point."""

@@ -217,6 +217,39 @@ def test_explicit_flattened_chunk_loop(dev, kind):
         m.generate(trajectory_prior=prior[:, :75].to(dev), maps_info=maps.to(dev))
 
 
+def test_latent_carrying_chunk_loop(dev):
+    """StrDiffDiT (best effort): sample starts from the prior, DDPM steps on x_from_z(denoiser latent), latent carried
+    between chunks.  Checked against the oracle's restatement (parity unpinned: the reference's denoiser for this variant is
+    missing from its tree)."""
+    from autodiffusion_amd import transition, synth
+    from oracle import nets, sampling, schedules as osched
+    cfg = transition.transition_config(frame_stack=10, z_dim=96, num_train_timesteps=100, num_inference_steps=5)
+    m = transition.StrDiffDiT(cfg)
+    synth.fill_module_(m, WSEED)
+    m = m.to(dev).eval()
+    B = 3
+    maps = synth.maps_info(B, ISEED)
+    prior = synth.trajectory_prior(B, ISEED) * 0.01            # clip_sample keeps |x0| <= 1: stay in the linear range
+    noise = synth.noise(B, (8, 4), (10, 4), NSEED)
+    out = m.generate(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), noise=noise.to(dev))["traj_logits"].cpu()
+    assert out.shape == (B, 80, 4)
+    full = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    sd = {k[len("transition_model.diffusion."):]: v for k, v in full.items() if k.startswith("transition_model.diffusion.")}
+    ac = np.cumprod(1.0 - osched.squaredcos_cap_v2(100).astype(np.float64))
+
+    def denoise(x, t, tran, pri):
+        tt = torch.full((x.shape[0],), int(t), dtype=torch.long)
+        return nets.variant_a_forward(sd, x, tt, maps, tran, pri)
+    z_emb = lambda z: z @ full["transition_model.z_emb.weight"].T + full["transition_model.z_emb.bias"]
+    x_from_z = lambda z: z @ full["transition_model.x_from_z.weight"].T + full["transition_model.x_from_z.bias"]
+    ref = sampling.transition_generate(denoise, z_emb, x_from_z, ac, 5, prior, full["init_z"], noise, 10, cfg.data_mean, cfg.data_std)
+    e = rel_err(out, ref)
+    print(f"StrDiffDiT: rel err {e:.2e}")
+    assert e < GATE
+    with pytest.raises(ValueError):
+        m.generate(trajectory_prior=prior[:, :75].to(dev), maps_info=maps.to(dev))
+
+
 def test_variant_a_state_dict_layout(dev):
     """The parameter/buffer names are the reference's (110 entries for fs=10)."""
     m = make_a(10)

@@ -169,6 +169,16 @@ def test_module_layouts_match_reference_names():
     assert tuple(ex.diffusion.diffusion.cond_pos_emb.shape) == (1, 791, 32)               # the reference's "# 791"
     assert tuple(ex.init_x.shape) == (40,)
     assert [int(r[0]) for r in ex.diffusion.schedule_rows()] == [90, 80, 70, 60, 50, 40, 30, 20, 10, 0]
+    from autodiffusion_amd import transition
+    st = transition.StrDiffDiT(transition.transition_config(frame_stack=10, z_dim=768))
+    sk = set(st.state_dict().keys())
+    for k in ("init_z", "data_mean", "data_std", "transition_model.x_from_z.weight", "transition_model.diffusion.head.weight"):
+        assert k in sk, k
+    assert tuple(st.init_z.shape) == (10, 768)
+    assert tuple(st.transition_model.x_from_z.weight.shape) == (4, 768)
+    assert tuple(st.transition_model.diffusion.head.weight.shape) == (768, 32)
+    assert tuple(st.transition_model.diffusion.cond_pos_emb.shape) == (1, 809, 32)
+    assert [int(r[0]) for r in st.transition_model.schedule_rows()] == [90, 80, 70, 60, 50, 40, 30, 20, 10, 0]
     with pytest.raises(ValueError):
         dit.Transformer_TrajDiffusionModel(dit.dit_config(64, 2, 4, "DDPM"))
     with pytest.raises(AssertionError):
