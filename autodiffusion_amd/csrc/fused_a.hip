@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, flo
         for (int t = 0; t < 4; ++t) {
             const int f = 4 * (j - 8) + t, g = f / 5, k = f % 5;
             const float m = st[6 * g], l = st[6 * g + 1];
-            e[t] = k == 0 ? m + log2f(l) : st[6 * g + 1 + k] / l;
+            e[t] = k == 0 ? m + __builtin_amdgcn_logf(l) : st[6 * g + 1 + k] * rcp_fast(l);      // v_log_f32 is log2, 1 ulp
         }
         v = make_float4(e[0], e[1], e[2], e[3]);
     }
