@@ -22,7 +22,7 @@ FLAG_NORMALIZE, FLAG_RESIDUAL, FLAG_INIT_ZERO, FLAG_NO_GRAPH = 1, 2, 4, 8
 
 EXPORTS = [
     "adx_abi_version", "adx_last_error",
-    "adx_op_timestep_embedding", "adx_op_linear", "adx_op_to_bf16", "adx_op_layernorm", "adx_op_attention",
+    "adx_op_timestep_embedding", "adx_op_linear", "adx_op_linear_staged", "adx_linear_stage_bytes", "adx_op_to_bf16", "adx_op_layernorm", "adx_op_attention",
     "adx_op_normalize", "adx_op_denormalize", "adx_op_sched_step",
     "adx_engine_create", "adx_engine_destroy", "adx_engine_set_tensor", "adx_engine_finalize", "adx_engine_reserve",
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
@@ -62,6 +62,8 @@ def load() -> C.CDLL:
         "adx_last_error": ([], C.c_char_p),
         "adx_op_timestep_embedding": ([p, i, i, p, p], i),
         "adx_op_linear": ([p, p, p, p, i, i, i, i, i, p], i),
+        "adx_op_linear_staged": ([p, p, p, p, i, i, i, i, i, p, C.c_size_t, p], i),
+        "adx_linear_stage_bytes": ([i, i, i, i], C.c_size_t),
         "adx_op_to_bf16": ([p, p, i64, p], i),
         "adx_op_layernorm": ([p, p, p, p, p, i64, f, i, i64, i, p, p], i),
         "adx_op_attention": ([p, p, p, p, i, i, i, i, i, i, f, i, p], i),

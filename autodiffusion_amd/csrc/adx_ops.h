@@ -35,7 +35,13 @@ struct LinearArgs {
     // column map of Y: col n -> (n / col_group) * col_stride + (n % col_group) + col_off (identity when col_group == 0)
     int col_group = 0, col_stride = 0, col_off = 0;
     int prec = PREC_F32;
+    // optional scratch (device memory, 16-byte aligned) for K-blocked bf16 planes of X (and of W unless Wblk is given):
+    // at least linear_stage_bytes(M, Wblk ? 0 : N, K, prec) bytes; enables the LDS-DMA form of the large-tile kernel
+    void* xstage = nullptr; size_t xstage_bytes = 0;
+    const void* Wblk = nullptr; const void* Wblk_lo = nullptr;      // W already in the K-blocked layout [K/16][N][16]
 };
+size_t linear_stage_bytes(int M, int N, int K, int prec);
+hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream);   // [N][K] bf16 -> [K/16][N][16]
 hipError_t linear(const LinearArgs& a, hipStream_t stream);        // picks linear_big when linear_big_ok(a)
 bool linear_big_ok(const LinearArgs& a);                             // large-tile bf16 kernel (gemm.hip) applies
 hipError_t linear_big(const LinearArgs& a, hipStream_t stream);

@@ -50,6 +50,8 @@ struct adx_engine {
     // activation workspace (one allocation, carved by a bump pointer at reserve())
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    void* xstage = nullptr;          // scratch for the staged (LDS-DMA) form of the large GEMMs, carved from ws by the engine
+    size_t xstage_bytes = 0;
     int max_batch = 0;
 
     // schedule

@@ -79,6 +79,7 @@ LinearArgs adx_engine::lin(const float* X, int64_t ldx, const std::string& wname
     a.M = M; a.N = N; a.K = K;
     a.act = act;
     a.prec = prec;
+    a.xstage = xstage; a.xstage_bytes = xstage_bytes;
     return a;
 }
 
@@ -236,6 +237,22 @@ ADX_API int adx_op_linear(const float* x, const void* w, const float* bias, floa
     a.X = x; a.ldx = K; a.W = w; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
     return done(linear(a, (hipStream_t)stream), "linear");
 }
+
+ADX_API int adx_op_linear_staged(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
+                                 int prec, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !w || !y) return fail(ADX_EINVAL, "linear_staged: null pointer");
+    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "linear_staged: bf16 precisions only");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(ADX_EINVAL, "linear_staged: empty shape");
+    if (!workspace || workspace_bytes < linear_stage_bytes(M, N, K, prec) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return fail(ADX_EINVAL, "linear_staged: workspace missing, misaligned or smaller than adx_linear_stage_bytes(M, N, K, prec)");
+    LinearArgs a;
+    if (prec == ADX_PREC_BF16X3) a.Wlo = reinterpret_cast<const uint16_t*>(w) + (int64_t)N * K;
+    a.X = x; a.ldx = K; a.W = w; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
+    a.xstage = workspace; a.xstage_bytes = workspace_bytes;
+    return done(linear(a, (hipStream_t)stream), "linear_staged");
+}
+
+ADX_API size_t adx_linear_stage_bytes(int M, int N, int K, int prec) { return linear_stage_bytes(M, N, K, prec); }
 
 ADX_API int adx_op_select_modes(const float* traj, int B, int M, int L, int D, int k, int em_iter, float* modes, float* weights,
                                 void* stream) {

@@ -101,6 +101,12 @@ struct EngineDiT final : adx_engine {
             take(&OB, R * d); take(&XA, R * d); take(&CA, R * d);
         }
         take(&XS0, R * C); take(&XS1, R * C); take(&MOUT, R * C);
+        {   // bf16 planes of the largest GEMM operands (X: R x 4d, W: 6d x 4d at most) for the staged kernel
+            float* stage = nullptr;
+            const size_t sb = cfg.precision == ADX_PREC_F32 ? 0 : adx::linear_stage_bytes((int)R, 6 * d, 4 * d, cfg.precision);
+            take(&stage, sb / sizeof(float));
+            xstage = dry ? nullptr : stage; xstage_bytes = sb;
+        }
         take(&TEB, (size_t)B * d); take(&TEH1, (size_t)std::max(B, 4096) * 2 * d); take(&TEH2, (size_t)std::max(B, 4096) * 2 * d);
         *bytes = off;
         return ADX_OK;

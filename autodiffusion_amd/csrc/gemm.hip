@@ -464,6 +464,254 @@ static hipError_t launch_ws(const LinearArgs& a, hipStream_t stream) {
     return a.in_act == ACT_SILU ? launch_ws2<X3, true>(a, stream) : launch_ws2<X3, false>(a, stream);
 }
 
+
+// ============================================================================================================
+// LDS-DMA form: 256x256 tile, 8 waves as 2x4, each a 128x64 sub-tile (4x2 accumulators of 32x32x16 MFMAs).  Both
+// operands arrive as K-BLOCKED bf16 planes -- plane[kb][row][16]: the 16 elements of K-step kb of every row, rows
+// contiguous -- written once per call by stage_x_kernel / stage_w_kernel (high halves, plus low halves for split
+// operands).  A K-step (k = 16) of a tile is then one contiguous run of 32-byte rows and is staged by 16-byte
+// global_load_lds copies of whole cache lines, with no vector-ALU work and no registers.
+//   * A ring of R LDS buffers (R = 4 x 32 KB with split operands, 8 x 16 KB without): the copies of R - 1 K-steps are in
+//     flight while one is multiplied -- the LDS-DMA path needs ~100 KB in flight per CU to run at its rate.
+//   * The fragments of K-step kt+1 are read from LDS while the MFMAs of step kt run (two register sets); one counted
+//     wait and one barrier per K-step.
+//   * LDS image: rows of 32 bytes; the 16-byte half c of row r sits at half c ^ ((r >> 3) & 1), which makes the
+//     ds_read_b128 fragment reads (32 rows x one half per half-wave) bank-conflict free.  LDS-DMA writes 64 lanes x 16 B
+//     to consecutive LDS bytes, so the swizzle is applied to the SOURCE address of each lane.
+// ============================================================================================================
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+struct StagedOperands {
+    const unsigned short *xh, *xl, *wh, *wl;      // K-blocked planes: [K/16][M][16] and [K/16][N][16]
+};
+
+constexpr int GT = 256;                           // tile rows and columns
+constexpr int GK = 16;                            // K-step
+constexpr int GROW_B = 32;                        // bytes per image row
+constexpr int GIMG_B = GT * GROW_B;               // 8 KB: one operand image (256 rows x 16 bf16)
+
+__device__ __forceinline__ int gswz(int row, int half) { return row * GROW_B + ((half ^ ((row >> 3) & 1)) << 4); }
+
+template <bool X3> struct Frags { bf16x8 ah[4], bh[2], al[4], bl[2]; };
+template <> struct Frags<false> { bf16x8 ah[4], bh[2]; };
+
+template <bool X3>
+__device__ __forceinline__ void load_frags(Frags<X3>& f, const unsigned char* st, int wr, int wc, int fr, int fc) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.bh[j] = *reinterpret_cast<const bf16x8*>(st + GIMG_B + gswz(wc * 64 + j * 32 + fr, fc));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.ah[i] = *reinterpret_cast<const bf16x8*>(st + gswz(wr * 128 + i * 32 + fr, fc));
+    if constexpr (X3) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.bl[j] = *reinterpret_cast<const bf16x8*>(st + 3 * GIMG_B + gswz(wc * 64 + j * 32 + fr, fc));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.al[i] = *reinterpret_cast<const bf16x8*>(st + 2 * GIMG_B + gswz(wr * 128 + i * 32 + fr, fc));
+    }
+}
+
+template <bool X3>
+__device__ __forceinline__ void mfma_frags(f32x16 (&acc)[4][2], const Frags<X3>& f) {
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+}
+
+template <bool X3, int ABL>
+__global__ __launch_bounds__(512, 1) void linear_glds_kernel(const LinearArgs a, const StagedOperands so, int tiles_n, int n_tiles) {
+    constexpr int STAGE_B = (X3 ? 4 : 2) * GIMG_B;                             // plain: [A][B]; split: [A_hi][B_hi][A_lo][B_lo]
+    constexpr int R = X3 ? 4 : 8;                                              // ring buffers: 128 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // R * STAGE_B
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int m0 = (tile / tiles_n) * GT, n0 = (tile % tiles_n) * GT;
+    const int M = a.M, N = a.N, K = a.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- copy plan: a slab = 32 image rows = 1 KB = one wave-instruction; wave w copies slab w of every image.
+    // Offsets are in elements of the planes, K-step 0.
+    const int r = wave * 32 + (lane >> 1);
+    const unsigned half = 8u * (unsigned)((lane & 1) ^ ((r >> 3) & 1));
+    const unsigned xoff = (unsigned)min(m0 + r, M - 1) * 16u + half, woff = (unsigned)min(n0 + r, N - 1) * 16u + half;
+    const unsigned xstep = (unsigned)M * 16u, wstep = (unsigned)N * 16u;      // elements per K-step of a plane
+    const int slab = wave * 1024;
+    const int nk = K / GK;
+    auto issue = [&](int kt) {                       // K-step kt (clamped: steps past the end repeat the last one) -> ring slot kt % R
+        unsigned char* st = smem + (kt % R) * STAGE_B;
+        const int kc = min(kt, nk - 1);
+        const unsigned xo = (unsigned)kc * xstep + xoff, wo = (unsigned)kc * wstep + woff;
+        dma16(so.xh + xo, st + slab);
+        dma16(so.wh + wo, st + GIMG_B + slab);
+        if constexpr (X3) {
+            dma16(so.xl + xo, st + 2 * GIMG_B + slab);
+            dma16(so.wl + wo, st + 3 * GIMG_B + slab);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int fr = lane & 31, fc = lane >> 5;
+
+    // wait until at most R - 2 K-steps of this wave's copies are outstanding
+    auto wait_copies = [&]() {
+        if constexpr (X3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // (R - 2) * 4 copies per K-step
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // (R - 2) * 2
+    };
+#pragma unroll
+    for (int t = 0; t < R; ++t) issue(t);
+    wait_copies();                                   // K-steps 0 and 1 have landed
+    __builtin_amdgcn_s_barrier();
+    Frags<X3> f0, f1;
+    load_frags<X3>(f0, smem, wr, wc, fr, fc);
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();                    // everyone holds step 0 in registers: its slot can be refilled
+    // Each K-step has a LOAD phase and a MULTIPLY phase, each closed by a barrier.  The two wave groups (wr = 0 / 1: the
+    // two waves that share a SIMD belong to different groups) run one phase apart -- group 1 takes one extra barrier here,
+    // group 0 one after the loop -- so on every SIMD one wave multiplies while the other reads fragments and starts copies,
+    // and a barrier is the hand-over of the matrix pipe instead of a point where it drains.
+    //   LOAD(kt):      start the copies of step kt+R into the slot of step kt (every wave read that slot in LOAD(kt-1), which
+    //                  ended at least one barrier ago for both groups); wait for this wave's copies of step kt+2; read the
+    //                  fragments of step kt+1 (every wave waited for its copies of kt+1 in LOAD(kt-1)).
+    //   MULTIPLY(kt):  MFMAs on the fragments of step kt.
+    // Copies and reads past the end repeat the last K-step.
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (!(ABL & 2)) { issue(kt + R); wait_copies(); }
+        if (!(ABL & 1)) load_frags<X3>(f1, smem + ((kt + 1) % R) * STAGE_B, wr, wc, fr, fc);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 4)) mfma_frags<X3>(acc, f0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 2)) { issue(kt + 1 + R); wait_copies(); }
+        if (!(ABL & 1)) load_frags<X3>(f0, smem + ((kt + 2) % R) * STAGE_B, wr, wc, fr, fc);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 4)) mfma_frags<X3>(acc, f1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // every wave is done reading, no copy is in flight
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+                     (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
+                     (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
+                     (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+    if (ABL & 8) {          // measurement aid: keep the accumulators alive with one store per lane instead of the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += acc[t >> 1][t & 1][q];
+        a.Y[(int64_t)min(m0 + wr * 128 + fr, M - 1) * a.ldy + min(n0 + wc * 64 + fc, N - 1)] = sum;
+    }
+#pragma unroll
+    for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
+        const int i = t >> 1, j = t & 1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
+        epilogue_patch(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec);
+    }
+}
+
+// X (fp32, row map, optional SiLU) -> K-blocked bf16 planes [K/16][M][16]: high halves and, when lo != nullptr,
+// bf16(x - high).  A thread converts 8 consecutive elements; threads run over the rows of one K-step first, so the
+// writes are contiguous.
+__global__ __launch_bounds__(256) void stage_x_kernel(const LinearArgs a, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_kb = (int64_t)a.M * 2;
+    if (i >= per_kb * (a.K >> 4)) return;
+    const int kb = (int)(i / per_kb), rem = (int)(i % per_kb), m = rem >> 1, c = rem & 1;
+    const float* src = a.X + row_of(a.xmap, m) * a.ldx + kb * 16 + c * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (a.in_act == ACT_SILU) v[e] = act_fn(v[e], ACT_SILU);
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+    }
+    *reinterpret_cast<bf16x8*>(hi + i * 8) = h;
+    if (lo) *reinterpret_cast<bf16x8*>(lo + i * 8) = l;
+}
+
+// W planes [N][K] (bf16 bits) -> K-blocked [K/16][N][16].
+__global__ __launch_bounds__(256) void stage_w_kernel(const unsigned short* __restrict__ w, int N, int K, unsigned short* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_kb = (int64_t)N * 2;
+    if (i >= per_kb * (K >> 4)) return;
+    const int kb = (int)(i / per_kb), rem = (int)(i % per_kb), n = rem >> 1, c = rem & 1;
+    *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(w + (int64_t)n * K + kb * 16 + c * 8);
+}
+
+template <bool X3>
+static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
+    constexpr size_t smem = (X3 ? 4 : 8) * (X3 ? 4 : 2) * (size_t)GIMG_B;      // ring of K-step buffers: 128 KB
+    static const int abl = [] { const char* e = getenv("ADX_GLDS_ABLATE"); return e ? atoi(e) : 0; }();
+    auto kern = &linear_glds_kernel<X3, 0>;
+    switch (abl) {          // measurement aid: bit 0 no LDS reads, bit 1 no copies, bit 2 no MFMAs, bit 3 no epilogue (results are wrong)
+        case 1: kern = &linear_glds_kernel<X3, 1>; break;
+        case 2: kern = &linear_glds_kernel<X3, 2>; break;
+        case 3: kern = &linear_glds_kernel<X3, 3>; break;
+        case 4: kern = &linear_glds_kernel<X3, 4>; break;
+        case 8: kern = &linear_glds_kernel<X3, 8>; break;
+        case 11: kern = &linear_glds_kernel<X3, 11>; break;
+        default: break;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return hipErrorInvalidValue;
+    const size_t xe = (size_t)a.M * a.K, we = (size_t)a.N * a.K;
+    unsigned short* base = reinterpret_cast<unsigned short*>(a.xstage);
+    StagedOperands so;
+    unsigned short* xh = base;
+    unsigned short* xl = X3 ? base + xe : nullptr;
+    so.xh = xh; so.xl = xl;
+    const int64_t nx = (int64_t)a.M * (a.K >> 3);
+    hipLaunchKernelGGL(stage_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, a, xh, xl);
+    if (a.Wblk) {
+        so.wh = reinterpret_cast<const unsigned short*>(a.Wblk);
+        so.wl = reinterpret_cast<const unsigned short*>(a.Wblk_lo);
+    } else {
+        unsigned short* wh = base + (X3 ? 2 : 1) * xe;
+        unsigned short* wl = X3 ? wh + we : nullptr;
+        const int64_t nw = (int64_t)a.N * (a.K >> 3);
+        hipLaunchKernelGGL(stage_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(a.W), a.N, a.K, wh);
+        if (X3) hipLaunchKernelGGL(stage_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(a.Wlo), a.N, a.K, wl);
+        so.wh = wh; so.wl = wl;
+    }
+    const int tiles_m = (a.M + GT - 1) / GT, tiles_n = (a.N + GT - 1) / GT;
+    const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
+    const int blocks = (int)((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, stream, a, so, tiles_n, (int)n_tiles);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // Shapes the large-tile kernel takes: bf16 operand modes, K a multiple of 64, 16-byte aligned rows, at least two row tiles.
@@ -493,12 +741,32 @@ static hipError_t launch_big(const LinearArgs& a, hipStream_t stream) {
     return a.in_act == ACT_SILU ? launch_big2<X3, WM, true>(a, stream) : launch_big2<X3, WM, false>(a, stream);
 }
 
+size_t linear_stage_bytes(int M, int N, int K, int prec) { return ((size_t)M + N) * K * 2 * (prec == PREC_BF16X3 ? 2 : 1); }
+
+hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream) {
+    if (!w || !out || N <= 0 || K <= 0 || (K % 32) != 0) return hipErrorInvalidValue;
+    const int64_t nw = (int64_t)N * (K >> 3);
+    hipLaunchKernelGGL(stage_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(w), N, K,
+                       reinterpret_cast<unsigned short*>(out));
+    return hipGetLastError();
+}
+
 hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     if (!linear_big_ok(a)) return hipErrorInvalidValue;
     static const int force_wm = [] { const char* e = getenv("ADX_GEMM_WM"); return e ? atoi(e) : 0; }();     // tuning knob
     // 256-row tiles halve the X traffic per flop; they need enough tiles to cover the chip (256 CUs, one workgroup each)
     const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + TN - 1) / TN);
     const bool tall = force_wm ? force_wm >= 4 : tiles256 >= 512;
+    // With a staging buffer from the caller both operands are re-laid as K-blocked bf16 planes once and the tiles are filled by
+    // LDS-DMA (256x256 tiles).  Measured against the register-staged kernels in one process: 0.8-0.9x their time when there
+    // are several rounds of tiles, wide N and long K (M=20480, N=4096, K=1024); equal or slower otherwise (a single column
+    // of tiles at N=256: 1.7x slower), so only those shapes take it.
+    static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();
+    const int64_t tiles_sq = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    if (!no_glds && force_wm == 0 && tiles_sq >= 900 && a.N >= 1024 && a.K >= 512 && a.xstage &&
+        a.xstage_bytes >= linear_stage_bytes(a.M, a.Wblk ? 0 : a.N, a.K, a.prec) && (reinterpret_cast<uintptr_t>(a.xstage) & 15) == 0 &&
+        (int64_t)a.M * a.K < ((int64_t)1 << 31) && (int64_t)a.N * a.K < ((int64_t)1 << 31))
+        return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);
     // measured: the wave-specialised form wins for single-pass bf16 (its producers keep up with 16 MFMAs per K-step per
     // consumer), the symmetric 256-row form for split operands (L2 -> CU staging bandwidth is the limit there either way)
     if (tall && (force_wm == 8 || (force_wm == 0 && a.prec == PREC_BF16)))

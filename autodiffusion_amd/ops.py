@@ -39,8 +39,9 @@ def prepare_weight(w: torch.Tensor, precision: str = "fp32") -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = _lib.ACT_NONE,
-           precision: str = "fp32", prepared_n: int = 0) -> torch.Tensor:
-    """``act(x w^T + bias)``.  With ``prepared_n`` > 0, ``w`` is already the result of ``prepare_weight`` for N = prepared_n."""
+           precision: str = "fp32", prepared_n: int = 0, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(x w^T + bias)``.  With ``prepared_n`` > 0, ``w`` is already the result of ``prepare_weight`` for N = prepared_n.
+    ``workspace`` (a CUDA byte tensor of at least ``linear_stage_bytes`` bytes, bf16 precisions) selects the staged entry."""
     lib = _lib.load()
     x = f32c(x)
     K = x.shape[-1]
@@ -50,8 +51,16 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     wd = w if prepared_n else prepare_weight(w, precision)
     b = f32c(bias) if bias is not None else None
     y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
-    check(lib.adx_op_linear(ptr(x), ptr(wd), ptr(b), ptr(y), M, N, K, act, prec, current_stream()), "linear")
+    if workspace is not None:
+        check(lib.adx_op_linear_staged(ptr(x), ptr(wd), ptr(b), ptr(y), M, N, K, act, prec, ptr(workspace),
+                                       workspace.numel() * workspace.element_size(), current_stream()), "linear_staged")
+    else:
+        check(lib.adx_op_linear(ptr(x), ptr(wd), ptr(b), ptr(y), M, N, K, act, prec, current_stream()), "linear")
     return y
+
+
+def linear_stage_bytes(M: int, N: int, K: int, precision: str) -> int:
+    return int(_lib.load().adx_linear_stage_bytes(int(M), int(N), int(K), _lib.PRECISIONS[precision]))
 
 
 def layernorm(x: torch.Tensor, gamma=None, beta=None, shift=None, scale=None, eps: float = 1e-5, relu: bool = False) -> torch.Tensor:

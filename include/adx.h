@@ -59,6 +59,14 @@ int adx_op_timestep_embedding(const int64_t* t, int n, int dim, float* out, void
  * libs/diffusionTransformer.py:38-47,63-76,134-165,189-193; libs/mlp.py:28,50). */
 int adx_op_linear(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
                   int prec, void* stream);
+/* Same product with a caller-provided scratch buffer (device memory, 16-byte aligned, at least
+ * adx_linear_stage_bytes(M, N, K, prec) bytes; bf16 precisions only): x and w are re-laid once as K-blocked bf16
+ * planes and large problems are tiled by LDS-DMA copies of whole cache lines instead of being converted again by every
+ * column tile.  Same reference
+ * call sites as adx_op_linear; results agree with it to the last bit (same products, same accumulation order). */
+int adx_op_linear_staged(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
+                         int prec, void* workspace, size_t workspace_bytes, void* stream);
+size_t adx_linear_stage_bytes(int M, int N, int K, int prec);
 int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 
 /* select_k_from_mc (models/utils.py:120-132 -> utils/modify_traj_utils.py: farthest_point_sample_PointCloud :8-30,

@@ -83,6 +83,29 @@ def test_op_linear_large_tile(dev, M, N, K, prec):
     assert torch.equal(yi, xi @ wi.T)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("M,N,K", [(8200, 2100, 128), (16384, 4096, 192)])
+def test_op_linear_staged(dev, M, N, K, prec):
+    """The staged entry (X converted to bf16 planes once, tiles filled by LDS-DMA) on shapes large enough to take that
+    kernel, ragged M and N included: equal to the unstaged entry bit for bit, and within the operand precision of fp64."""
+    from autodiffusion_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ws = torch.empty(ops.linear_stage_bytes(M, N, K, prec) + 64, dtype=torch.uint8, device=dev)
+    y0 = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec)
+    y1 = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec, workspace=ws)
+    y2 = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec, workspace=ws)
+    assert torch.equal(y1, y2)
+    assert torch.equal(y0, y1)
+    xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if prec == "bf16" else (x.double(), w.double())
+    ref = torch.nn.functional.gelu(xr @ wr.T + b.double(), approximate="tanh").float()
+    assert rel_err(y1.cpu(), ref.cpu()) < 2e-5
+    with pytest.raises(_lib.AdxError):
+        ops.linear(x, w, b, _lib.ACT_NONE, prec, workspace=ws[:1024])
+
+
 def test_op_linear_asymmetric_identity(dev):
     """A = I against an asymmetric W catches a transposed accumulator layout."""
     from autodiffusion_amd import ops
