@@ -407,6 +407,31 @@ def test_shard_invariance(dev):
             assert rel_err(full.cpu(), _oracle_generate(da, B, fs, N)) < GATE
 
 
+def test_full_size_properties(dev):
+    """The bench configuration at full size (4096 scenarios, DDIM 50 of 100, split-bf16 operands), through properties that
+    do not need a full-size oracle: two runs are bit-identical; the first and the last rows equal what a 3-row batch of the same
+    global rows gives (rows do not see their neighbours, whatever the batch and the tile they fall in); and the first rows are
+    within the ADE gate of the fp32 CPU oracle."""
+    from autodiffusion_amd import metrics, synth
+    fs, N, ns, B = 10, 100, 50, 4096
+    da = _make_da(fs, N, "bf16x3", "reference", dev, ns)
+    maps = synth.maps_info(B, ISEED).to(dev)
+    prior = synth.trajectory_prior(B, ISEED).to(dev)
+    noise = synth.noise(B, (8, ns), (fs, 4), NSEED).to(dev)
+    full = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].clone()
+    again = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"]
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, again)
+    for lo in (0, B - 3):
+        part = da.generate(trajectory_prior=prior[lo:lo + 3].contiguous(), maps_info=maps[lo:lo + 3].contiguous(),
+                           noise=noise[:, :, lo:lo + 3].contiguous())["traj_logits"]
+        assert torch.equal(full[lo:lo + 3], part), f"rows {lo}..{lo + 2} depend on the batch they run in"
+    ref = _oracle_generate(da, 2, fs, N, ns)
+    ade = float(metrics.ade_fde(full[:2].cpu(), ref)["ade8"].max())
+    print(f"full size: ADE of rows 0-1 vs fp32 oracle {ade:.2e} m")
+    assert ade < 1e-2
+
+
 @pytest.mark.parametrize("sampler", ["ddpm10", "ddim50of100"])
 def test_bf16_final_ade(dev, sampler):
     """bf16-MFMA engine against the fp32 oracle, same noise: final trajectories within 1e-2 m ADE.
