@@ -188,28 +188,33 @@ constexpr int PACK_VECS = 13;   // float4 per lane per 32-row tile: exactly the 
 // which needs five floats instead of six and one exponential instead of two, and cannot overflow to NaN
 // (2^(c - s) = inf gives g = 0).
 __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, float4* __restrict__ packed, int64_t n_tiles) {
+    // one thread per (tile, lane): the 13 vectors that lane will load
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_tiles * PACK_VECS * 64) return;
-    const int lane = (int)(i & 63), j = (int)((i >> 6) % PACK_VECS);
-    const int64_t tile = (i >> 6) / PACK_VECS;
+    if (i >= n_tiles * 64) return;
+    const int lane = (int)(i & 63);
+    const int64_t tile = i >> 6;
     const int64_t n_rows = (int64_t)a.B * a.L;
     const int64_t row = min(tile * 32 + (lane & 31), n_rows - 1);
     const int h = lane >> 5;
-    float4 v;
-    if (j < 4) v = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * j);
-    else if (j < 8) v = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * (j - 4));
-    else {
-        const float* st = a.state + row * (NH * 6) + h * 24;
-        float e[4];
+    float4* dst = packed + tile * (PACK_VECS * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int f = 4 * (j - 8) + t, g = f / 5, k = f % 5;
-            const float m = st[6 * g], l = st[6 * g + 1];
-            e[t] = k == 0 ? m + __builtin_amdgcn_logf(l) : st[6 * g + 1 + k] * rcp_fast(l);      // v_log_f32 is log2, 1 ulp
-        }
-        v = make_float4(e[0], e[1], e[2], e[3]);
+    for (int g = 0; g < 4; ++g) {
+        dst[64 * g] = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * g);
+        dst[64 * (4 + g)] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * g);
     }
-    packed[i] = v;
+    const float4* sp = reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24);      // 96 bytes: 4 x {m, l, o[4]}
+    float st[24], e[20];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) { const float4 t = sp[v]; st[4 * v] = t.x; st[4 * v + 1] = t.y; st[4 * v + 2] = t.z; st[4 * v + 3] = t.w; }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float inv = rcp_fast(st[6 * g + 1]);
+        e[5 * g] = st[6 * g] + __builtin_amdgcn_logf(st[6 * g + 1]);      // v_log_f32 is log2, 1 ulp
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[5 * g + 1 + k] = st[6 * g + 2 + k] * inv;
+    }
+#pragma unroll
+    for (int v = 0; v < 5; ++v) dst[64 * (8 + v)] = make_float4(e[4 * v], e[4 * v + 1], e[4 * v + 2], e[4 * v + 3]);
 }
 
 __device__ __forceinline__ void load_row(RowIn& in, const float4* __restrict__ p) {
@@ -365,7 +370,7 @@ size_t enc_rows_packed_bytes(int B, int L) { return (size_t)(((int64_t)B * L + 3
 
 hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream) {
     if (a.B <= 0 || a.L <= 0 || !a.packed || !a.x0 || !a.q || !a.state) return hipErrorInvalidValue;
-    const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32, n = tiles * PACK_VECS * 64;
+    const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32, n = tiles * 64;
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, const_cast<float4*>(a.packed), tiles);
     return hipGetLastError();
 }

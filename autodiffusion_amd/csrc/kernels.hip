@@ -404,6 +404,31 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttentionArgs a) 
         for (int jj = 0; jj < nk; jj += 8) {
             float s[8];
             float mx = -INFINITY;
+            if (a.mask_off < 0 && jj + 8 <= nk) {          // whole block visible (workgroup-uniform): no per-key tests
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float d = qv[0] * Ks[(jj + u) * DH];
+#pragma unroll
+                    for (int c = 1; c < DH; ++c) d = fmaf(qv[c], Ks[(jj + u) * DH + c], d);
+                    s[u] = d;
+                    mx = fmaxf(mx, d);
+                }
+                const float mn = fmaxf(m, mx);
+                const float alpha = exp2_fast(m - mn);
+                float ps = 0.f;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) o[c] *= alpha;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float p = exp2_fast(s[u] - mn);
+                    ps += p;
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) o[c] = fmaf(p, Vs[(jj + u) * DH + c], o[c]);
+                }
+                l = fmaf(l, alpha, ps);
+                m = mn;
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int j = jj + u;
@@ -720,15 +745,30 @@ __global__ __launch_bounds__(256) void attn_rows_kernel(const RowsAttnArgs a) {
             if (r < nk) KVs[r][c] = *reinterpret_cast<const float4*>((c < 8 ? Kb : Vb) + (int64_t)(j0 + r) * a.ldk + 4 * (c & 7));
         }
         __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < nk; ++j) {
-            const float4 kk = KVs[j][h], vv = KVs[j][8 + h];
-            const float sc = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
-            const float mn = fmaxf(m, sc);
-            const float al = exp2_fast(m - mn), p = exp2_fast(sc - mn);
-            l = fmaf(l, al, p);
-            o.x = fmaf(o.x, al, p * vv.x); o.y = fmaf(o.y, al, p * vv.y);
-            o.z = fmaf(o.z, al, p * vv.z); o.w = fmaf(o.w, al, p * vv.w);
+        // four keys per softmax update: one running-max update and one rescale per block (keys past the tile repeat its
+        // last key -- a real score, so the maximum stays valid -- with their probability forced to zero)
+        for (int j = 0; j < nk; j += 4) {
+            float sc[4];
+            float4 vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ju = min(j + u, nk - 1);
+                const float4 kk = KVs[ju][h];
+                vv[u] = KVs[ju][8 + h];
+                sc[u] = fmaf(q.x, kk.x, fmaf(q.y, kk.y, fmaf(q.z, kk.z, q.w * kk.w)));
+            }
+            const float mn = fmaxf(fmaxf(fmaxf(m, sc[0]), fmaxf(sc[1], sc[2])), sc[3]);
+            const float al = exp2_fast(m - mn);
+            float p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = j + u < nk ? exp2_fast(sc[u] - mn) : 0.f;
+            l = fmaf(l, al, (p[0] + p[1]) + (p[2] + p[3]));
+            o.x *= al; o.y *= al; o.z *= al; o.w *= al;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                o.x = fmaf(p[u], vv[u].x, o.x); o.y = fmaf(p[u], vv[u].y, o.y);
+                o.z = fmaf(p[u], vv[u].z, o.z); o.w = fmaf(p[u], vv[u].w, o.w);
+            }
             m = mn;
         }
     }
