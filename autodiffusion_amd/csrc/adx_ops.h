@@ -214,6 +214,7 @@ struct TailMfmaArgs {
     float* x_next = nullptr;
     float* model_out = nullptr;
     int B = 0, L = 0, T = 0, n_dec = 0;
+    int split = 0;                    // 1: the image was packed in the split-bf16 form (tail_mfma_pack_block(..., split = 1))
 };
 struct TailMfmaVecLayout {
     int e_bo, e_ln2_g, e_ln2_b, e_b1, e_b2, din_b, pos, layer0, layer_size;
@@ -224,7 +225,7 @@ int tail_mfma_vec_floats();
 int tail_mfma_blocks(int n_dec);
 size_t tail_mfma_image_bytes(int n_dec);
 TailMfmaVecLayout tail_mfma_vec_layout();
-hipError_t tail_mfma_pack_block(const float* W, int ldw, int row0, int col0, void* image, int block, hipStream_t stream);
+hipError_t tail_mfma_pack_block(const float* W, int ldw, int row0, int col0, void* image, int block, int split, hipStream_t stream);
 hipError_t tail_mfma_pack_ends(const float* Win, const float* Whead, void* image, hipStream_t stream);
 hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream);
 

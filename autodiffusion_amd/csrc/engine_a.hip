@@ -61,6 +61,7 @@ struct EngineA final : adx_engine {
     float* tail_w = nullptr;
     TailArgs tail_tpl;
     bool tail_mfma_ok = false;         // the one-wavefront-per-item MFMA form applies (in_dim = out_dim = 4)
+    int tail_split = 0;                // its maps on memory rows run on split-bf16 operands (bf16 precision modes) instead of fp32 MFMAs
     void* tailm_image = nullptr;
     float* tailm_vecs = nullptr;
 
@@ -89,6 +90,10 @@ struct EngineA final : adx_engine {
         split_cache = fused && fast4 && cfg.map_cond && nmaps > 0 && 2 * NP <= 64 && !(whole && whole[0] == '1');
         const char* no_mfma = getenv("ADX_TAIL_VALU");       // tuning knob: force the VALU form of the tail
         tail_mfma_ok = tail_ok && Cin == 4 && !(no_mfma && no_mfma[0] == '1');
+        {
+            const char* f32_tail = getenv("ADX_TAIL_F32");       // tuning / fallback switch: fp32 MFMAs in every precision mode
+            tail_split = cfg.precision != ADX_PREC_F32 && !(f32_tail && f32_tail[0] == '1');
+        }
     }
 
     std::vector<ParamSpec> expected_params() const override {
@@ -200,8 +205,9 @@ struct EngineA final : adx_engine {
         ADX_HIP(hipMemsetAsync(tailm_vecs, 0, sizeof(float) * tail_mfma_vec_floats(), s));
         const TailMfmaVecLayout v = tail_mfma_vec_layout();
         int blk = 0;
+        bool mem_side = true;              // blocks that act on memory rows take the split-bf16 form in the bf16 precision modes
         auto block = [&](const std::string& w, int ldw, int row0, int col0) {
-            return tail_mfma_pack_block(P(w), ldw, row0, col0, tailm_image, blk++, s);
+            return tail_mfma_pack_block(P(w), ldw, row0, col0, tailm_image, blk++, mem_side ? tail_split : 0, s);
         };
         auto vec = [&](const float* src, int off, int n) {
             return hipMemcpyAsync(tailm_vecs + off, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s);
@@ -225,9 +231,14 @@ struct EngineA final : adx_engine {
         for (int l = 0; l < n_dec; ++l) {
             const std::string p = "decoder.layers." + std::to_string(l);
             const int o = v.layer0 + l * v.layer_size;
+            mem_side = false;
             for (int i = 0; i < 3; ++i) ADX_HIP(block(p + ".self_attn.in_proj_weight", d, 32 * i, 0));
             ADX_HIP(block(p + ".self_attn.out_proj.weight", d, 0, 0));
-            for (int i = 0; i < 3; ++i) ADX_HIP(block(p + ".multihead_attn.in_proj_weight", d, 32 * i, 0));
+            for (int i = 0; i < 3; ++i) {
+                mem_side = i > 0;          // query from the trajectory tokens, keys / values from the memory rows
+                ADX_HIP(block(p + ".multihead_attn.in_proj_weight", d, 32 * i, 0));
+            }
+            mem_side = false;
             ADX_HIP(block(p + ".multihead_attn.out_proj.weight", d, 0, 0));
             ADX_HIP(ffn(p));
             ADX_HIP(vec(P(p + ".norm1.weight"), o + v.ln1_g, d)); ADX_HIP(vec(P(p + ".norm1.bias"), o + v.ln1_b, d));
@@ -253,7 +264,7 @@ struct EngineA final : adx_engine {
         if (tail_mfma_ok) {
             TailMfmaArgs t;
             t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = z; t.coef = coef;
-            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec;
+            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_split;
             ADX_HIP(tail_mfma(t, s));
             return ADX_OK;
         }
