@@ -120,6 +120,40 @@ __device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, con
     return acc;
 }
 
+// The split-bf16 product with the weight fragments fetched separately, so that the LDS reads can be issued well before
+// the MFMAs that consume them (ahead of a block of vector work) instead of right in front of them.
+struct WFrag { bf16x8 ah[2], al[2]; };
+
+__device__ __forceinline__ WFrag load_w(const unsigned char* lds_img, int tile, int lane) {
+    const unsigned short* whi = reinterpret_cast<const unsigned short*>(lds_img) + (tile * 2 * 64 + lane) * 8;
+    const unsigned short* wlo = whi + NFRAG_BF * 64 * 8;
+    WFrag w;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        w.ah[s] = *reinterpret_cast<const bf16x8*>(whi + s * 64 * 8);
+        w.al[s] = *reinterpret_cast<const bf16x8*>(wlo + s * 64 * 8);
+    }
+    return w;
+}
+
+__device__ __forceinline__ f32x16 mm_w(const WFrag& w, const f32x16& in, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 bhv, blv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = in[8 * s + j];
+            const __bf16 hi = (__bf16)v;
+            bhv[j] = hi;
+            blv[j] = (__bf16)(v - (float)hi);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.ah[s], blv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.al[s], bhv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.ah[s], bhv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), with Phi(-t) = 2^q(t) and q a degree-6 polynomial fitted to
 // log2 Phi(-t) on [0, 5.6] (weighted minimax for the error of the product; beyond 5.6 the term is below 1e-7 and t is
 // clamped).  |error| <= 3e-7 over the whole line, with one transcendental and no division: the exponential and the
@@ -297,17 +331,40 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         // ---- y2 = y1 + W2 gelu(W1 LN(y1) + b1) + b2, one 32-wide slice of the hidden layer at a time
         const f32x16 hn = layer_norm32(y1, g2, be2, h);
         f32x16 acc2 = zero16();
+        if constexpr (PREC == PREC_BF16X3) {
+            WFrag w1 = load_w(img, tile_base(1), lane);
 #pragma unroll 1
-        for (int nt = 0; nt < 4; ++nt) {
-            f32x16 f = mm<PREC>(img, tile_base(1) + nt, hn, zero16(), lane);
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x16 f = mm_w(w1, hn, zero16());
+                const WFrag w2 = load_w(img, tile_base(2) + nt, lane);          // lands under the GELU
+                float4 bb[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b = *reinterpret_cast<const float4*>(b1 + 32 * nt + 8 * g + 4 * h);
-                const f32x2 lo = gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
-                const f32x2 hi = gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
-                f[4 * g + 0] = lo.x; f[4 * g + 1] = lo.y; f[4 * g + 2] = hi.x; f[4 * g + 3] = hi.y;
+                for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const float4*>(b1 + 32 * nt + 8 * g + 4 * h);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = bb[g];
+                    const f32x2 lo = gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
+                    const f32x2 hi = gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
+                    f[4 * g + 0] = lo.x; f[4 * g + 1] = lo.y; f[4 * g + 2] = hi.x; f[4 * g + 3] = hi.y;
+                }
+                w1 = load_w(img, tile_base(1) + min(nt + 1, 3), lane);          // lands under the MFMAs below
+                __builtin_amdgcn_sched_barrier(0);
+                acc2 = mm_w(w2, f, acc2);
             }
-            acc2 = mm<PREC>(img, tile_base(2) + nt, f, acc2, lane);
+        } else {
+#pragma unroll 1
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x16 f = mm<PREC>(img, tile_base(1) + nt, hn, zero16(), lane);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = *reinterpret_cast<const float4*>(b1 + 32 * nt + 8 * g + 4 * h);
+                    const f32x2 lo = gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
+                    const f32x2 hi = gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
+                    f[4 * g + 0] = lo.x; f[4 * g + 1] = lo.y; f[4 * g + 2] = hi.x; f[4 * g + 3] = hi.y;
+                }
+                acc2 = mm<PREC>(img, tile_base(2) + nt, f, acc2, lane);
+            }
         }
         f32x16 y2;
 #pragma unroll
