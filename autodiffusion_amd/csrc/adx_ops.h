@@ -214,6 +214,7 @@ struct TailMfmaArgs {
     float* x_next = nullptr;
     float* model_out = nullptr;
     int B = 0, L = 0, T = 0, n_dec = 0;
+    const float* pos = nullptr;       // pos_emb [T][32]: read from here when T + 1 > 16 (the table in `vecs` holds 16 rows)
     int split = 0;                    // 1: the image was packed in the split-bf16 form (tail_mfma_pack_block(..., split = 1))
 };
 struct TailMfmaVecLayout {

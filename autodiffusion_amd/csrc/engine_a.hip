@@ -89,7 +89,7 @@ struct EngineA final : adx_engine {
         const char* whole = getenv("ADX_CHUNK_CACHE_WHOLE");   // tuning knob: rebuild the whole layer-0 cache per chunk
         split_cache = fused && fast4 && cfg.map_cond && nmaps > 0 && 2 * NP <= 64 && !(whole && whole[0] == '1');
         const char* no_mfma = getenv("ADX_TAIL_VALU");       // tuning knob: force the VALU form of the tail
-        tail_mfma_ok = tail_ok && Cin == 4 && !(no_mfma && no_mfma[0] == '1');
+        tail_mfma_ok = fused && T + 1 <= 96 && Cin == 4 && Cout == 4 && n_dec <= 4 && !(no_mfma && no_mfma[0] == '1');
         {
             const char* f32_tail = getenv("ADX_TAIL_F32");       // tuning / fallback switch: fp32 MFMAs in every precision mode
             tail_split = cfg.precision != ADX_PREC_F32 && !(f32_tail && f32_tail[0] == '1');
@@ -227,7 +227,7 @@ struct EngineA final : adx_engine {
         ADX_HIP(vec(P(e1 + ".norm2.weight"), v.e_ln2_g, d)); ADX_HIP(vec(P(e1 + ".norm2.bias"), v.e_ln2_b, d));
         ADX_HIP(vec(P(e1 + ".linear1.bias"), v.e_b1, 4 * d)); ADX_HIP(vec(P(e1 + ".linear2.bias"), v.e_b2, d));
         ADX_HIP(vec(P("input_emb.bias"), v.din_b, d));
-        ADX_HIP(vec(P("pos_emb"), v.pos, T * d));
+        ADX_HIP(vec(P("pos_emb"), v.pos, std::min(T, 16) * d));
         for (int l = 0; l < n_dec; ++l) {
             const std::string p = "decoder.layers." + std::to_string(l);
             const int o = v.layer0 + l * v.layer_size;
@@ -265,6 +265,7 @@ struct EngineA final : adx_engine {
             TailMfmaArgs t;
             t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = z; t.coef = coef;
             t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_split;
+            t.pos = P("pos_emb");
             ADX_HIP(tail_mfma(t, s));
             return ADX_OK;
         }
@@ -496,7 +497,7 @@ struct EngineA final : adx_engine {
             prof_begin(2, s);
             ADX_HIP(attention_few_queries(fused_attn_args(B), s));
             prof_end(s);
-            if (tail_ok && io.x_next && stepped) {
+            if ((tail_ok || tail_mfma_ok) && io.x_next && stepped) {
                 prof_begin(3, s);
                 ADX_TRY(launch_tail(B, x, io.z, steps_dev + step, io.x_next, out, s));
                 prof_end(s);
@@ -611,7 +612,7 @@ struct EngineA final : adx_engine {
                 ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s));
             } else if (stage == 2) ADX_HIP(attention_few_queries(fused_attn_args(B), s));
             else if (stage == 3) {
-                if (!tail_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
+                if (!tail_ok && !tail_mfma_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
                 ADX_TRY(launch_tail(B, XS0, nullptr, steps_dev, XS1, MOUT, s));
             } else if (stage == 4) ADX_TRY(build_chunk_cache(B, s));
             else if (stage == 5) ADX_TRY(build_map_cache(B, s));

@@ -1,4 +1,5 @@
-// MFMA form of the fused variant-A tail (see tail_a.hip for what the tail covers): one WAVEFRONT per batch item.
+// MFMA form of the fused variant-A tail (see tail_a.hip for what the tail covers): one WAVEFRONT per batch item (up to 16
+// rows per item), or one wavefront per 16-row tile of an item and one workgroup per item (up to 96 rows).
 //
 // The tail is a chain of 32-wide linear maps on at most 16 rows (T+1 memory rows, T trajectory tokens) of each item.
 // Every map runs transposed on the fp32 matrix cores, Y^T = W X^T, as 16x16x4 MFMA tiles: M = 16 output features,
@@ -212,20 +213,21 @@ __device__ __forceinline__ void store_kv(float* kv, const A8& k, const A8& v, in
     }
 }
 
-// softmax attention of this lane's two heads (q and q + 4) over keys j < nk with j <= n + mask_off
-__device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int n, int q, int nk, int mask_off) {
+// softmax attention of this lane's two heads (q and q + 4) over keys j < nk with j <= row + mask_off (row = the lane's row
+// index among the item's rows)
+__device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int row, int q, int nk, int mask_off) {
     const float sc = 0.5f * LOG2E_M;                    // 1 / sqrt(head_dim 4), in log2 units
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     A8 o;
     o.t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     o.t[1] = o.t[0];
-    const int last = n + mask_off;
+    const int last = row + mask_off;
 #pragma unroll 2
     for (int j = 0; j < nk; ++j) {
-        const float* row = kv + j * KV_LD + 4 * q;
+        const float* kr = kv + j * KV_LD + 4 * q;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const f32x4 kk = ld4(row + 16 * t), vv = ld4(row + 32 + 16 * t);
+            const f32x4 kk = ld4(kr + 16 * t), vv = ld4(kr + 32 + 16 * t);
             float s = (qv.t[t][0] * kk[0] + qv.t[t][1] * kk[1] + qv.t[t][2] * kk[2] + qv.t[t][3] * kk[3]) * sc;
             s = j <= last ? s : -INFINITY;
             const float mn = fmaxf(m[t], s);            // key 0 is visible to every row, so mn is finite from j = 0 on
@@ -240,27 +242,37 @@ __device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int n, int q
     return o;
 }
 
-template <bool BF>
-__global__ __launch_bounds__(256, 4) void tail_mfma_kernel(const TailMfmaArgs a) {
+// NW = 1: a workgroup of four wavefronts, one batch item each (at most 16 rows per item).
+// NW > 1: one batch item per workgroup of NW wavefronts; wavefront w owns rows 16 w .. 16 w + 15 of the item (memory rows
+//         and trajectory tokens alike), keys / values of all rows meet in one LDS tile and the workgroup barriers around
+//         each attention replace the wave-private ordering.  Rows past the end are clamped copies that nobody can see.
+template <bool BF, int NW>
+__global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail_mfma_kernel(const TailMfmaArgs a) {
+    constexpr int NT = NW == 1 ? 256 : 64 * NW;
     __shared__ __attribute__((aligned(16))) float vec[V_TOTAL];
-    __shared__ __attribute__((aligned(16))) float kv_all[4][16 * KV_LD];
-    for (int i = threadIdx.x; i < V_TOTAL; i += 256) vec[i] = a.vecs[i];
+    __shared__ __attribute__((aligned(16))) float kv_all[NW == 1 ? 4 : 1][(NW == 1 ? 16 : 16 * NW) * KV_LD];
+    for (int i = threadIdx.x; i < V_TOTAL; i += NT) vec[i] = a.vecs[i];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     // waves past the batch recompute the last item and store nothing
-    const int item = blockIdx.x * 4 + wave;
+    const int item = NW == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    const int rb = NW == 1 ? 0 : 16 * wave;              // first row of this wavefront's tile
     const bool live = item < a.B;
     const int b = min(item, a.B - 1);
-    float* kv = kv_all[wave];
+    float* kv = kv_all[NW == 1 ? wave : 0];
     const int T = a.T, TR = a.T + 1;
     const float4* img = reinterpret_cast<const float4*>(a.image) + lane;
+    auto tile_sync = [&]() {
+        if constexpr (NW == 1) wave_sync();              // the K/V tile is private to the wave: order its LDS traffic only
+        else __syncthreads();
+    };
 
     WStream ws;
     ws.init(img + 3 * SLOT);                             // slots 0..2: input embedding and head, read directly
     // ---- remainder of the last encoder layer on the T+1 visible rows -> memory rows XM
     A8 att, xm;
     {
-        const int64_t row = (int64_t)b * a.L + min(n, TR - 1);
+        const int64_t row = (int64_t)b * a.L + min(rb + n, TR - 1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             att.t[t] = ld4(a.att1 + row * 32 + 16 * t + 4 * q);
@@ -271,18 +283,19 @@ __global__ __launch_bounds__(256, 4) void tail_mfma_kernel(const TailMfmaArgs a)
     xm = ffn<BF>(ws, xm, ln8(xm, vec + V_E_LN2G, vec + V_E_LN2B, q), vec + V_E_B1, vec + V_E_B2, q);
     const Opnd<BF> xmo = prep<BF>(xm);               // the memory rows feed the K/V projections of every decoder layer
     // ---- decoder input: input_emb(x_t) + pos_emb
-    const int nt = min(n, T - 1);
+    const int nt = min(rb + n, T - 1);
     const float* xrow = a.x + ((int64_t)b * T + nt) * 4;
     A8 y;
     {
         const float4 w = img[0];
         const float xin = xrow[q];
-        const float* pos = vec + V_POS + nt * 32;
+        const float* pos = NW == 1 ? vec + V_POS + nt * 32 : a.pos + nt * 32;      // the table in LDS holds 16 rows
         y.t[0] = ld4(vec + V_DIN_B + 4 * q) + ld4(pos + 4 * q);
         y.t[1] = ld4(vec + V_DIN_B + 16 + 4 * q) + ld4(pos + 16 + 4 * q);
         y.t[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, xin, y.t[0], 0, 0, 0);
         y.t[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, xin, y.t[1], 0, 0, 0);
     }
+    const int nk_self = min(T, rb + 16), nk_cross = min(TR, rb + 17);      // keys this tile's rows can see
 #pragma unroll 1
     for (int l = 0; l < a.n_dec; ++l) {
         const float* lv = vec + V_LAYER0 + l * VL_SIZE;
@@ -294,20 +307,20 @@ __global__ __launch_bounds__(256, 4) void tail_mfma_kernel(const TailMfmaArgs a)
         const A8 qs = mm32<false>(ws, h, bias8(lv + VL_BQKV, q));
         const A8 ks = mm32<false>(ws, h, bias8(lv + VL_BQKV + 32, q));
         const A8 vs = mm32<false>(ws, h, bias8(lv + VL_BQKV + 64, q));
-        wave_sync();                                     // the K/V tile is private to the wave: order its LDS traffic only
-        store_kv(kv, ks, vs, n, q);
-        wave_sync();
-        A8 at = attend(kv, qs, n, q, T, 0);
+        tile_sync();
+        store_kv(kv + rb * KV_LD, ks, vs, n, q);
+        tile_sync();
+        A8 at = attend(kv, qs, rb + n, q, nk_self, 0);
         y = mm32<false>(ws, prep<false>(at), add8(y, bias8(lv + VL_BO, q)));
         // cross-attention: query i sees memory rows 0..i+1; keys / values come from the memory rows (split form allowed)
         h = prep<false>(ln8(y, lv + VL_LN2G, lv + VL_LN2B, q));
         const A8 qc = mm32<false>(ws, h, bias8(lv + VL_BQ, q));
         const A8 km = mm32<BF>(ws, xmo, bias8(lv + VL_BKV, q));
         const A8 vm = mm32<BF>(ws, xmo, bias8(lv + VL_BKV + 32, q));
-        wave_sync();
-        store_kv(kv, km, vm, n, q);
-        wave_sync();
-        at = attend(kv, qc, n, q, TR, 1);
+        tile_sync();
+        store_kv(kv + rb * KV_LD, km, vm, n, q);
+        tile_sync();
+        at = attend(kv, qc, rb + n, q, nk_cross, 1);
         y = mm32<false>(ws, prep<false>(at), add8(y, bias8(lv + VL_BO2, q)));
         // feed-forward
         y = ffn<false>(ws, y, ln8(y, lv + VL_LN3G, lv + VL_LN3B, q), lv + VL_B1, lv + VL_B2, q);
@@ -317,9 +330,9 @@ __global__ __launch_bounds__(256, 4) void tail_mfma_kernel(const TailMfmaArgs a)
     f32x4 out = ld4(vec + V_HEAD_B + 4 * q);
     out = mfma4(img[1 * SLOT], hf.t[0], out);
     out = mfma4(img[2 * SLOT], hf.t[1], out);
-    if (live && q == 0 && n < T) {
+    if (live && q == 0 && rb + n < T) {
         const StepCoef k = *a.coef;
-        const int64_t gi = ((int64_t)b * T + n) * 4;
+        const int64_t gi = ((int64_t)b * T + rb + n) * 4;
         const f32x4 xv = ld4(xrow);
         f32x4 r;
 #pragma unroll
@@ -403,11 +416,20 @@ hipError_t tail_mfma_pack_ends(const float* Win, const float* Whead, void* image
     return hipGetLastError();
 }
 
-hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream) {
-    if (a.B <= 0 || a.T <= 0 || a.T + 1 > 16 || a.n_dec < 0 || a.n_dec > 4 || !a.image || !a.vecs) return hipErrorInvalidValue;
-    if (a.split) hipLaunchKernelGGL(tail_mfma_kernel<true>, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(tail_mfma_kernel<false>, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+template <bool BF>
+static hipError_t launch_tail_mfma(const TailMfmaArgs& a, hipStream_t stream) {
+    if (a.T + 1 <= 16) {
+        hipLaunchKernelGGL((tail_mfma_kernel<BF, 1>), dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+    } else {
+        if (!a.pos) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((tail_mfma_kernel<BF, 6>), dim3(a.B), dim3(384), 0, stream, a);
+    }
     return hipGetLastError();
+}
+
+hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.T <= 0 || a.T + 1 > 96 || a.n_dec < 0 || a.n_dec > 4 || !a.image || !a.vecs) return hipErrorInvalidValue;
+    return a.split ? launch_tail_mfma<true>(a, stream) : launch_tail_mfma<false>(a, stream);
 }
 
 }  // namespace adx

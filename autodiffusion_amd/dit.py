@@ -193,9 +193,16 @@ class DiffusionWrapper(nn.Module):
             self.register_buffer(k, v)
 
     def schedule_rows(self, determin: bool):
-        b = {k: getattr(self, k).detach().float().cpu() for k in schedules.BUFFER_NAMES}
-        return schedules.ddpm_rows(b, "pred_noise", clamp=float(self.max_action), noise_at_every_step=True,
-                                   stochastic=not determin)
+        """Recomputed only when a schedule buffer changed: reading the buffers back synchronises the device."""
+        stamp = (tuple((getattr(self, k).data_ptr(), getattr(self, k)._version) for k in schedules.BUFFER_NAMES),
+                 float(self.max_action), bool(determin))
+        cache = self.__dict__.setdefault("_rows_cache", {})
+        if cache.get("stamp") != stamp:
+            b = {k: getattr(self, k).detach().float().cpu() for k in schedules.BUFFER_NAMES}
+            cache["rows"] = schedules.ddpm_rows(b, "pred_noise", clamp=float(self.max_action), noise_at_every_step=True,
+                                                stochastic=not determin)
+            cache["stamp"] = stamp
+        return cache["rows"]
 
     def forward(self, hidden_state, batch_size=0, label=None, info_dict=None, get_inter=False, **kwargs):
         if self.training:

@@ -202,10 +202,18 @@ class DiffusionWrapper(nn.Module):
         return {k: getattr(self, k).detach().float().cpu() for k in schedules.BUFFER_NAMES}
 
     def schedule_rows(self):
-        b = self._buffers_cpu()
-        if self.is_ddim_sampling:
-            return schedules.ddim_rows(b, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
-        return schedules.ddpm_rows(b, self.objective)
+        """Coefficient rows of the registered schedule buffers; recomputed only when a buffer (or a sampling option)
+        changed -- reading the buffers back is a device synchronisation, which must not sit in every generate()."""
+        stamp = (tuple((getattr(self, k).data_ptr(), getattr(self, k)._version) for k in schedules.BUFFER_NAMES),
+                 self.objective, bool(self.is_ddim_sampling), self.sampling_timesteps, float(self.ddim_sampling_eta))
+        if getattr(self, "_rows_stamp", None) != stamp:
+            b = self._buffers_cpu()
+            if self.is_ddim_sampling:
+                self._rows = schedules.ddim_rows(b, self.objective, self.sampling_timesteps, float(self.ddim_sampling_eta))
+            else:
+                self._rows = schedules.ddpm_rows(b, self.objective)
+            self._rows_stamp = stamp
+        return self._rows
 
     def flags(self) -> int:
         return (_lib.FLAG_NORMALIZE if self.auto_normalize_data else 0) | (_lib.FLAG_RESIDUAL if self.residual else 0)
