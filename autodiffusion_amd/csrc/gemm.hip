@@ -127,7 +127,10 @@ constexpr int EP_LD = 36;     // floats per row of a wave's 32x32 epilogue patch
 // Y rows m_base .. m_base+31, columns n_base .. n_base+31 from a 32x32 patch of raw accumulators in LDS.
 __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float* ep, int m_base, int n_base, int lane, bool vec) {
     const int c4 = (lane & 7) * 4, n = n_base + c4;
-#pragma unroll 1
+    // the bias of a lane's four columns is the same for every row: fetched once, outside the (rolled) row loop
+    float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec && a.bias && n < a.N) bvec = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll 2
     for (int rr = 0; rr < 4; ++rr) {
         const int row = rr * 8 + (lane >> 3), m = m_base + row;
         if (m >= a.M || n >= a.N) continue;
@@ -136,7 +139,7 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
         const int64_t yrow = row_of(a.ymap, m);
         const float* posrow = a.pos ? a.pos + (int64_t)((m % a.pos_period) + a.pos_off) * a.ldp : nullptr;
         if (vec) {
-            if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+            v[0] += bvec.x; v[1] += bvec.y; v[2] += bvec.z; v[3] += bvec.w;
             if (posrow) { const float4 p = *reinterpret_cast<const float4*>(posrow + n); v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], a.act);
