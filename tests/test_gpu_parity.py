@@ -388,6 +388,31 @@ def _make_da(fs, N, prec, init, dev, n_sample=None):
     return da.to(dev).eval()
 
 
+@pytest.mark.parametrize("fs", [5, 16, 20, 40])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_frame_stacks_between_goldens(dev, fs, prec):
+    """Frame stacks the goldens do not cover (every divisor of 80 is legal): fs = 5 (6 rows per scenario in the fused tail),
+    16 and 20 (17 / 21 rows: two tiles of the multi-tile tail, the second nearly empty), 40 (three tiles).  fp32 against the
+    CPU oracle within the per-step gate; split-bf16 against the fp32 engine within the ADE gate."""
+    from autodiffusion_amd import metrics, synth
+    B, N = 3, 4
+    # the ADE gate is stated for the reference's own initialisation (see test_bf16_final_ade); the fp32 comparison uses the
+    # seeded all-random weights, which exercise every bias and LayerNorm parameter
+    da = _make_da(fs, N, prec, "seeded" if prec == "fp32" else "reference", dev)
+    noise = synth.noise(B, (80 // fs, N), (fs, 4), NSEED).to(dev)
+    out = da.generate(trajectory_prior=synth.trajectory_prior(B, ISEED).to(dev), maps_info=synth.maps_info(B, ISEED).to(dev),
+                      noise=noise)["traj_logits"].cpu()
+    ref = _oracle_generate(da, B, fs, N)
+    if prec == "fp32":
+        e = rel_err(out, ref)
+        print(f"fs={fs} fp32: rel err {e:.2e}")
+        assert e < GATE
+    else:
+        ade = float(metrics.ade_fde(out, ref)["ade8"].max())
+        print(f"fs={fs} bf16x3: ADE {ade:.2e} m")
+        assert ade < 1e-2
+
+
 def test_shard_invariance(dev):
     """A row's result does not depend on its batch neighbours: what multi-GPU sharding relies on."""
     from autodiffusion_amd import synth
