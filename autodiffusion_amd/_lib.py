@@ -18,7 +18,7 @@ ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY, ACT_SILU = range(6)
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 VARIANT_A, VARIANT_DIT, VARIANT_MMDIT = 0, 1, 2
-FLAG_NORMALIZE, FLAG_RESIDUAL, FLAG_INIT_ZERO, FLAG_NO_GRAPH = 1, 2, 4, 8
+FLAG_NORMALIZE, FLAG_RESIDUAL, FLAG_INIT_ZERO, FLAG_NO_GRAPH, FLAG_KEEP_MAPS = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "adx_abi_version", "adx_last_error",

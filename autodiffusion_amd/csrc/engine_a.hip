@@ -61,6 +61,7 @@ struct EngineA final : adx_engine {
     float* tail_w = nullptr;
     TailArgs tail_tpl;
     bool tail_mfma_ok = false;         // the one-wavefront-per-item MFMA form applies (in_dim = out_dim = 4)
+    int maps_batch = -1;               // batch size of the last sample() call that embedded maps_info (ADX_FLAG_KEEP_MAPS)
     int tail_split = 0;                // its maps on memory rows run on split-bf16 operands (bf16 precision modes) instead of fp32 MFMAs
     void* tailm_image = nullptr;
     float* tailm_vecs = nullptr;
@@ -632,6 +633,7 @@ struct EngineA final : adx_engine {
     int denoise(int B, const float* x, const int64_t* t, const float* maps, const float* tran, const float* prior, float* out,
                 hipStream_t s) {
         ADX_TRY(check_ready(B, "denoise_a"));
+        maps_batch = -1;                    // the map caches of a previous sampling call no longer match the embedding
         ADX_TRY(embed_maps(B, maps, s));
         ADX_TRY(embed_prior(B, tran, prior, s));
         ADX_HIP(timestep_embedding(t, B, d, TE, d, s));
@@ -707,9 +709,14 @@ struct EngineA final : adx_engine {
         char key[256];
         snprintf(key, sizeof key, "s|%d|%p|%p|%p|%p|%d|%p|%p|%p|%u|%d", B, (const void*)maps, (const void*)tran, (const void*)prior,
                  (const void*)noise, n_noise, (void*)out, (void*)trace_x, (void*)trace_out, flags, schedule_version);
+        const bool keep = (flags & ADX_FLAG_KEEP_MAPS) != 0;
+        if (keep && maps_batch != B) { set_error("sample_a: ADX_FLAG_KEEP_MAPS without a previous call at this batch size"); return ADX_EINVAL; }
+        maps_batch = B;
         return run(key, flags, s, [&](hipStream_t cs) -> int {
-            ADX_TRY(embed_maps(B, maps, cs));
-            ADX_TRY(build_map_cache(B, cs));
+            if (!keep) {
+                ADX_TRY(embed_maps(B, maps, cs));
+                ADX_TRY(build_map_cache(B, cs));
+            }
             return sample_body(B, tran, prior, noise, n_noise, out, (int64_t)T * Cin, trace_x, trace_out, flags, cs);
         });
     }

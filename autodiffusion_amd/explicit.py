@@ -55,10 +55,24 @@ class TrajDiffusion(nn.Module):
         lead = (n,) if n_chunks is None else (n_chunks, n)
         return torch.randn(*lead, batch, 1, self.cfg.trajectory_dim * self.cfg.frame_stack, device=device)
 
+    def _staging(self, B: int, n_noise: int, device):
+        """Persistent per-(batch, device) buffers for the per-chunk tensors: the engine keys its captured hipGraph on the
+        pointers it is given, and the chunk loop would otherwise hand it fresh tensors (a new capture) for every chunk."""
+        key = (B, n_noise, str(device))
+        if getattr(self, "_stage_key", None) != key:
+            W = self.cfg.trajectory_dim * self.cfg.frame_stack
+            f = dict(device=device, dtype=torch.float32)
+            self._stage = (torch.empty(B, 1, W, **f), torch.empty(B, 1, W, **f), torch.empty(n_noise, B, 1, W, **f), torch.empty(B, 1, W, **f))
+            self._stage_key = key
+        return self._stage
+
     @torch.no_grad()
-    def generate(self, label, transition_info, trajectory_prior, maps_info, noise: Optional[torch.Tensor] = None):
+    def generate(self, label, transition_info, trajectory_prior, maps_info, noise: Optional[torch.Tensor] = None,
+                 same_maps: bool = False):
         """label (B, fs*4) [shape only], transition_info (B, fs*4) or (B, 1, fs*4), trajectory_prior (B, fs*4),
-        maps_info (B, 788, maps_dim) -> (B, fs*4).  ``noise``: (1 + draws, B, 1, fs*4), default fresh N(0, 1)."""
+        maps_info (B, 788, maps_dim) -> (B, fs*4).  ``noise``: (1 + draws, B, 1, fs*4), default fresh N(0, 1).
+        ``same_maps``: maps_info is the tensor of the previous call (the next chunk of the same trajectories), so its
+        embedding and attention caches are kept."""
         B = label.shape[0]
         if transition_info.dim() == 2:
             transition_info = transition_info.unsqueeze(1)
@@ -68,8 +82,10 @@ class TrajDiffusion(nn.Module):
         if noise is None:
             noise = self.make_noise(B, prior.device)
         maps = _lib.f32c(maps_info) if self.diffusion.map_cond else None
-        out = eng.sample_a(maps, _lib.f32c(transition_info), _lib.f32c(prior), _lib.f32c(noise), 0)
-        return out.squeeze(1)
+        tb, pb, nb, ob = self._staging(B, noise.shape[0], prior.device)
+        tb.copy_(transition_info.reshape(tb.shape)); pb.copy_(prior.reshape(pb.shape)); nb.copy_(noise.reshape(nb.shape))
+        eng.sample_a(maps, tb, pb, nb, _lib.FLAG_KEEP_MAPS if same_maps else 0, out=ob)
+        return ob.squeeze(1).clone()
 
     def forward(self, label, transition_info, trajectory_prior, maps_info):
         raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
@@ -122,7 +138,7 @@ class ExplicitDiT(nn.Module):
         label = torch.empty(B, width, device=prior.device)          # shape only
         preds = []
         for c in range(n_chunks):
-            transition = self.diffusion.generate(label, transition, prior[:, c].contiguous(), maps_info, noise=noise[c])
+            transition = self.diffusion.generate(label, transition, prior[:, c].contiguous(), maps_info, noise=noise[c], same_maps=c > 0)
             preds.append(transition)
         out = torch.stack(preds, dim=1).reshape(B, S, C)
         return {"traj_logits": self._unnormalize_x(out).to(torch.float32)}

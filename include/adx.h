@@ -40,6 +40,8 @@ enum { ADX_VARIANT_A = 0, ADX_VARIANT_DIT = 1, ADX_VARIANT_MMDIT = 2 };
 #define ADX_FLAG_RESIDUAL 2u    /* add the raw prior to the un-normalised sample (TrajRefiner.py:382-384) */
 #define ADX_FLAG_INIT_ZERO 4u   /* x_N = 0 instead of noise[0] (determin=True, diffusion_decoder.py:390-393) */
 #define ADX_FLAG_NO_GRAPH 8u    /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define ADX_FLAG_KEEP_MAPS 16u  /* adx_sample_a: maps_info is unchanged since the previous adx_sample_a call with this batch
+                                   size (the chunks of one trajectory, ExplicitDiT.py:164-190): keep its embedding and caches */
 
 int adx_abi_version(void);
 const char* adx_last_error(void);

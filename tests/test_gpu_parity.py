@@ -537,6 +537,12 @@ def test_errors(dev):
     w.train()
     with pytest.raises(NotImplementedError):
         w({}, torch.zeros(1, 10, 4))
+    # keeping the map caches needs a previous sampling call at the same batch size
+    from autodiffusion_amd import explicit, synth
+    td = explicit.TrajDiffusion(explicit.explicit_config(frame_stack=10, num_inference_steps=2)).to(dev).eval()
+    z = torch.zeros(2, 40, device=dev)
+    with pytest.raises(_lib.AdxError, match="KEEP_MAPS"):
+        td.generate(z, z, z, synth.maps_info(2, ISEED).to(dev), same_maps=True)
 
 
 # ------------------------------------------------------------------ multi-modal reduction (select_k_from_mc)
