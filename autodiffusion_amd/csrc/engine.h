@@ -105,6 +105,10 @@ int adx_engine::run(const std::string& key, unsigned flags, hipStream_t stream, 
     if ((flags & ADX_FLAG_NO_GRAPH) || profiling) return body(stream);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
+        if (graphs.size() >= 16) {      // a caller that never reuses its buffers: bound the cache (a replay may still be running)
+            ADX_HIP(hipDeviceSynchronize());
+            drop_graphs();
+        }
         if (!cap_stream) ADX_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
         ADX_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         int rc = body(cap_stream);
