@@ -10,4 +10,17 @@ __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float rsqrt_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// x + (value of x in lane ^ 16) and x + (value in lane ^ 32) with the gfx950 row / half swaps: vector-ALU instructions,
+// where __shfl_xor goes through the LDS crossbar (ds_bpermute) and costs an LDS round trip inside a dependent chain.
+__device__ __forceinline__ float xor16_add(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_add(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 }  // namespace adx

@@ -185,12 +185,12 @@ __device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gam
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += y[i];
-    s += __shfl_xor(s, 32, 64);
+    s = xor32_add(s);
     const float mean = s * (1.0f / 32.0f);
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const float t = y[i] - mean; q = fmaf(t, t, q); }
-    q += __shfl_xor(q, 32, 64);
+    q = xor32_add(q);
     const float rstd = rsqrt_fast(fmaf(q, 1.0f / 32.0f, 1e-5f));
     f32x16 o;
 #pragma unroll

@@ -174,8 +174,7 @@ __device__ __forceinline__ A8 ln8(const A8& y, const float* g, const float* b, i
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += y.t[t][r];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = xor32_add(xor16_add(s));
     const float mean = s * (1.0f / 32.0f);
     A8 d;
     float v = 0.f;
@@ -183,8 +182,7 @@ __device__ __forceinline__ A8 ln8(const A8& y, const float* g, const float* b, i
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { d.t[t][r] = y.t[t][r] - mean; v = fmaf(d.t[t][r], d.t[t][r], v); }
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v = xor32_add(xor16_add(v));
     const float rstd = rsqrt_fast(fmaf(v, 1.0f / 32.0f, 1e-5f));
     A8 o;
 #pragma unroll
