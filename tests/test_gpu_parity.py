@@ -413,6 +413,29 @@ def test_frame_stacks_between_goldens(dev, fs, prec):
         assert ade < 1e-2
 
 
+@pytest.mark.parametrize("fs", [10, 80])
+@pytest.mark.parametrize("B", [1, 5, 33])
+def test_fused_equals_dense_ragged_batches(dev, fs, B):
+    """Batch sizes that leave the last workgroup / row tile of every fused kernel partly empty (1, 5, 33 scenarios): the fused
+    path (elide 3) against the dense path (elide 0, itself checked against the goldens), fp32, same noise."""
+    from autodiffusion_amd import refiner, synth
+    N = 3
+    outs = []
+    for elide in (3, 0):
+        cfg = refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective="pred_noise", beta_schedule="cosine", elide=elide)
+        da = refiner.DiffusionAugmentation(cfg)
+        synth.fill_module_(da.diffusion, WSEED)
+        with torch.no_grad():
+            da.init_x.copy_(synth.seeded_param("init_x", (fs, 4), WSEED))
+        da = da.to(dev).eval()
+        noise = synth.noise(B, (80 // fs, N), (fs, 4), NSEED).to(dev)
+        outs.append(da.generate(trajectory_prior=synth.trajectory_prior(B, ISEED).to(dev), maps_info=synth.maps_info(B, ISEED).to(dev),
+                                noise=noise)["traj_logits"].cpu())
+    e = rel_err(outs[0], outs[1])
+    print(f"fs={fs} B={B}: fused vs dense rel err {e:.2e}")
+    assert e < 1e-4
+
+
 def test_shard_invariance(dev):
     """A row's result does not depend on its batch neighbours: what multi-GPU sharding relies on."""
     from autodiffusion_amd import synth
