@@ -570,8 +570,9 @@ __global__ __launch_bounds__(256) void attn_fewq_kernel(const AttentionArgs a) {
 //
 // A lane takes its keys four at a time: one running-max update, one rescale of (l, o) and five exponentials per
 // query per block instead of two exponentials and a rescale per key.  One block of K/V is in flight per lane
-// while the other is processed (four resident waves per SIMD cover the rest of the latency).  Keys past the end re-read the last key (its score is a real score, so the running
-// maximum stays valid) and their probabilities are forced to zero.
+// while the other is processed (four resident waves per SIMD cover the rest of the latency).  Keys past the end
+// re-read the last key (its score is a real score, so the running maximum stays valid) and their probabilities are
+// forced to zero.
 namespace {
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(256, 4) void attn_fewq3_kernel(const AttentionArgs 
         const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
         const float p0 = __shfl_xor(o0, 32, 64), p1 = __shfl_xor(o1, 32, 64);
         const float p2 = __shfl_xor(o2, 32, 64), p3 = __shfl_xor(o3, 32, 64);
-        const float mn = fmaxf(m, m2);                          // finite: key lane 0 or 1 of wave 0.. saw a real key; -inf only if both empty
+        const float mn = fmaxf(m, m2);                          // -inf only if neither key lane of this wave saw a key
         const float a1 = mn == -INFINITY ? 0.f : exp2_fast(m - mn), a2 = mn == -INFINITY ? 0.f : exp2_fast(m2 - mn);
         if (lane < 32) {
             float* r = red[wave][qg * NQ + i][h];
