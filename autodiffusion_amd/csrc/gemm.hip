@@ -124,43 +124,105 @@ __device__ __forceinline__ void stash(const Stage<X3, WM>& s, const StagePlan<X3
 
 constexpr int EP_LD = 36;     // floats per row of a wave's 32x32 epilogue patch (144 B: 16-byte aligned, staggers banks)
 
+// The activation of a lane's epilogue values with the switch OUTSIDE the element loop (one uniform branch per patch).
+template <int RP>
+__device__ __forceinline__ void act_patch(float (&v)[RP][4], int act) {
+#define ADX_ACT_ALL(A)                                      \
+    _Pragma("unroll") for (int rr = 0; rr < RP; ++rr)       \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[rr][e] = act_fn(v[rr][e], A);
+    switch (act) {
+        case ACT_RELU: ADX_ACT_ALL(ACT_RELU) break;
+        case ACT_GELU_ERF: ADX_ACT_ALL(ACT_GELU_ERF) break;
+        case ACT_GELU_TANH: ADX_ACT_ALL(ACT_GELU_TANH) break;
+        case ACT_LEAKY: ADX_ACT_ALL(ACT_LEAKY) break;
+        case ACT_SILU: ADX_ACT_ALL(ACT_SILU) break;
+        default: break;
+    }
+#undef ADX_ACT_ALL
+}
+
 // Y rows m_base .. m_base+31, columns n_base .. n_base+31 from a 32x32 patch of raw accumulators in LDS.
-__device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float* ep, int m_base, int n_base, int lane, bool vec) {
+// Vector form: a lane owns four columns of rows (lane >> 3) + 8 rr, handled RP rows at a time.  Every load of a pass
+// (position table, gate, residual) is issued before its first store and the stores go out back to back: vector-memory
+// operations retire in order, so a load issued after a store waits for that store to complete.  With RP = 4 nothing in
+// a patch waits for a store; RP = 2 halves the registers and waits once per patch when there is a gate or a residual.
+// lds_bias: the bias vector (zeros without one) in LDS; bias_reg: this lane's four bias values, fetched by the caller before
+// its first patch -- either keeps the bias load (which would wait for the stores of the previous patch) out of the patch.
+template <int RP>
+__device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float* ep, int m_base, int n_base, int lane, bool vec,
+                                               const float* lds_bias = nullptr, const float4* bias_reg = nullptr) {
     const int c4 = (lane & 7) * 4, n = n_base + c4;
-    // the bias of a lane's four columns is the same for every row: fetched once, outside the (rolled) row loop
-    float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (vec && a.bias && n < a.N) bvec = *reinterpret_cast<const float4*>(a.bias + n);
-#pragma unroll 2
+    if (vec) {
+        if (n >= a.N) return;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 bvec = zero;
+        if (bias_reg) bvec = *bias_reg;
+        else if (lds_bias) bvec = *reinterpret_cast<const float4*>(lds_bias + n);
+        else if (a.bias) bvec = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+        for (int r0 = 0; r0 < 4; r0 += RP) {
+            float v[RP][4];
+            float4 g[RP], r[RP];
+            float* yp[RP];
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const int row = (r0 + i) * 8 + (lane >> 3), m = m_base + row;
+                const int mc = m < a.M ? m : a.M - 1;                 // clamped rows are loaded and computed but not stored
+                const int64_t yrow = row_of(a.ymap, mc);
+                yp[i] = m < a.M ? a.Y + yrow * a.ldy + n : nullptr;
+                const float4 raw = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+                float4 p = zero;
+                if (a.pos) p = *reinterpret_cast<const float4*>(a.pos + (int64_t)((mc % a.pos_period) + a.pos_off) * a.ldp + n);
+                g[i] = zero; r[i] = zero;
+                if (a.gate) g[i] = *reinterpret_cast<const float4*>(a.gate + yrow * a.ldg + n);
+                if (a.res) r[i] = *reinterpret_cast<const float4*>(a.res + yrow * a.ldr + n);
+                v[i][0] = raw.x + bvec.x + p.x; v[i][1] = raw.y + bvec.y + p.y; v[i][2] = raw.z + bvec.z + p.z; v[i][3] = raw.w + bvec.w + p.w;
+            }
+            act_patch<RP>(v, a.act);
+            if (a.gate) {
+#pragma unroll
+                for (int i = 0; i < RP; ++i) { v[i][0] *= g[i].x; v[i][1] *= g[i].y; v[i][2] *= g[i].z; v[i][3] *= g[i].w; }
+            }
+            if (a.res) {
+#pragma unroll
+                for (int i = 0; i < RP; ++i) { v[i][0] += r[i].x; v[i][1] += r[i].y; v[i][2] += r[i].z; v[i][3] += r[i].w; }
+            }
+#pragma unroll
+            for (int i = 0; i < RP; ++i)
+                if (yp[i]) *reinterpret_cast<float4*>(yp[i]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+        return;
+    }
+#pragma unroll 1
     for (int rr = 0; rr < 4; ++rr) {
         const int row = rr * 8 + (lane >> 3), m = m_base + row;
         if (m >= a.M || n >= a.N) continue;
         const float4 raw = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
-        float v[4] = {raw.x, raw.y, raw.z, raw.w};
         const int64_t yrow = row_of(a.ymap, m);
         const float* posrow = a.pos ? a.pos + (int64_t)((m % a.pos_period) + a.pos_off) * a.ldp : nullptr;
-        if (vec) {
-            v[0] += bvec.x; v[1] += bvec.y; v[2] += bvec.z; v[3] += bvec.w;
-            if (posrow) { const float4 p = *reinterpret_cast<const float4*>(posrow + n); v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_fn(v[e], a.act);
-            if (a.gate) { const float4 g = *reinterpret_cast<const float4*>(a.gate + yrow * a.ldg + n); v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w; }
-            if (a.res) { const float4 r = *reinterpret_cast<const float4*>(a.res + yrow * a.ldr + n); v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-            *reinterpret_cast<float4*>(a.Y + yrow * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
 #pragma unroll 1
-            for (int e = 0; e < 4; ++e) {
-                const int ne = n + e;
-                if (ne >= a.N) break;
-                float x = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-                if (a.bias) x += a.bias[ne];
-                if (posrow) x += posrow[ne];
-                x = act_fn(x, a.act);
-                if (a.gate) x *= a.gate[yrow * a.ldg + ne];
-                if (a.res) x += a.res[yrow * a.ldr + ne];
-                const int nc = a.col_group ? (ne / a.col_group) * a.col_stride + (ne % a.col_group) + a.col_off : ne;
-                a.Y[yrow * a.ldy + nc] = x;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int ne = n + e;
+            if (ne >= a.N) break;
+            float x = e == 0 ? raw.x : e == 1 ? raw.y : e == 2 ? raw.z : raw.w;
+            if (a.bias) x += a.bias[ne];
+            if (posrow) x += posrow[ne];
+            x = act_fn(x, a.act);
+            if (a.gate) x *= a.gate[yrow * a.ldg + ne];
+            if (a.res) x += a.res[yrow * a.ldr + ne];
+            const int nc = a.col_group ? (ne / a.col_group) * a.col_stride + (ne % a.col_group) + a.col_off : ne;
+            a.Y[yrow * a.ldy + nc] = x;
         }
+    }
+}
+
+// The bias of the two 32-column patches of a wave's 64-column sub-tile, as this lane will use them in the vector epilogue.
+__device__ __forceinline__ void load_patch_bias(const LinearArgs& a, int n_base, int lane, bool vec, float4 (&bv)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n_base + j * 32 + (lane & 7) * 4;
+        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec && a.bias && n < a.N) bv[j] = *reinterpret_cast<const float4*>(a.bias + n);
     }
 }
 
@@ -295,12 +357,14 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(c
                      (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+    float4 bv[2];
+    load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = t >> 1, j = t & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
-        epilogue_patch(a, ep, m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, vec);
+        epilogue_patch<4>(a, ep, m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
     }
 }
 
@@ -439,12 +503,14 @@ __global__ __launch_bounds__(512, 1) void linear_ws_kernel(const LinearArgs a, i
                      (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+    float4 bv[2];
+    load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int i = t >> 1, j = t & 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
-        epilogue_patch(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec);
+        epilogue_patch<4>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
     }
 }
 
@@ -487,6 +553,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ void dma16(const unsigned short* g, unsigned char* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+// The same copy issued from inline assembly, for kernels that overlap copies with LDS reads of OTHER buffers: the compiler
+// makes every LDS read wait for all vector-memory operations while a copy it knows of is in flight (the copy may alias
+// the read), which would serialise them.  The kernel orders the copies itself with counted waits and barriers.
+__device__ __forceinline__ void dma16_unordered(const unsigned short* g, unsigned char* l) {
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)l);
+    unsigned keep;          // m0 is restored: the compiler does not expect inline assembly to change it
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(g) : "memory");
 }
 
 struct StagedOperands {
@@ -634,12 +710,14 @@ __global__ __launch_bounds__(512, 1) void linear_glds_kernel(const LinearArgs a,
             for (int q = 0; q < 16; ++q) sum += acc[t >> 1][t & 1][q];
         a.Y[(int64_t)min(m0 + wr * 128 + fr, M - 1) * a.ldy + min(n0 + wc * 64 + fc, N - 1)] = sum;
     }
+    float4 bv[2];
+    load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
 #pragma unroll
     for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
         const int i = t >> 1, j = t & 1;
 #pragma unroll
         for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
-        epilogue_patch(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec);
+        epilogue_patch<4>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
     }
 }
 
@@ -715,6 +793,178 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ============================================================================================================
+// Row-stationary form for short K (K = 16 KS <= 256) and very many rows: a workgroup of 8 waves owns 256 rows of X for ALL
+// N output columns, so X is read, converted and split exactly once (the tiled kernels above do that once per column of
+// tiles) and no X bytes pass through LDS at all.
+//   * Each wave turns its 32 rows of X into MFMA fragments that stay in registers for the whole kernel: KS x 4 VGPRs of
+//     high halves, as many again of low halves with split operands (128 VGPRs at K = 256).
+//   * W is walked in column tiles of 32: the bf16 rows of a tile (all of K: KS KB per operand image) are copied global -> LDS
+//     by 16-byte LDS-DMA into one of two buffers, laid out [k16 step][k half][column] so that the fragment read of a
+//     step is one contiguous KB.  A tile costs 3 KS (split) or KS dependent 32x32x16 MFMAs per wave and one 32x32 epilogue.
+//   * The two waves of a SIMD (wave w and w + 4) belong to different groups that run half a tile apart: while one
+//     multiplies tile j the other runs the epilogue (bias, activation, gate, residual, 16-byte stores) of the tile it
+//     finished before, so the matrix pipe always has a wave issuing and the epilogue costs no matrix time.  Two
+//     barriers per column tile hand the roles over; group 1 also starts the copies of the next tile.
+// ============================================================================================================
+constexpr int ROWS_MAX_N = 8192;                  // the bias vector sits in LDS
+
+template <bool X3, int KS>
+__device__ __forceinline__ void rows_mul_tile(f32x16& acc, const bf16x8 (&ah)[KS], const bf16x8 (&al)[X3 ? KS : 1], const unsigned char* wb, int lane) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // W fragments run two k16 steps ahead of the MFMAs (three register sets): an LDS read takes longer than the three
+    // MFMAs of a step, and the scheduler left to itself reads each step right before it is used.
+    constexpr int AHEAD = 2;
+    bf16x8 bh[AHEAD + 1], bl[X3 ? AHEAD + 1 : 1];
+    auto read = [&](int s) {
+        bh[s % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(wb + (s * 64 + lane) * 16);
+        if constexpr (X3) bl[s % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(wb + KS * 1024 + (s * 64 + lane) * 16);
+    };
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) read(s);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if (s + AHEAD < KS) read(s + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = s % (AHEAD + 1);
+        if constexpr (X3) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[c], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[c], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool X3, bool SILU, int KS>
+__global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a) {
+    constexpr int IMG_B = KS * 1024;                          // one operand image of a 32-column tile
+    constexpr int WBUF_B = (X3 ? 2 : 1) * IMG_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // 2 * WBUF_B + 8 epilogue patches
+    const int M = a.M, N = a.N, K = a.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fc = lane >> 5;
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int m0 = (int)blockIdx.x * 256 + wave * 32;
+    float* ep = reinterpret_cast<float*>(smem + 2 * WBUF_B) + wave * (32 * EP_LD);
+    float* lbias = reinterpret_cast<float*>(smem + 2 * WBUF_B) + 8 * 32 * EP_LD;          // N floats, rounded up to 4
+    for (int i = tid; i < ((N + 3) & ~3); i += 512) lbias[i] = (a.bias && i < N) ? a.bias[i] : 0.f;        // visible after the first barrier
+    // Workgroups start at different column tiles and wrap around: they all advance at the same rate, and with a common
+    // order every store in flight on the chip would land in the same 128 bytes of each 4 N-byte row (one memory channel).
+    const int nt = (N + 31) / 32;
+    const int jrot = (int)((blockIdx.x * 7u) % (unsigned)nt);
+    auto col_tile = [&](int j) { const int c = j + jrot; return c >= nt ? c - nt : c; };
+
+    // ---- this wave's 32 rows of X -> register fragments (lane: row fr, elements 16 s + 8 fc .. + 7 of every k16 step s)
+    bf16x8 ah[KS], al[X3 ? KS : 1];
+    {
+        const float* xp = a.X + row_of(a.xmap, min(m0 + fr, M - 1)) * a.ldx + 8 * fc;          // clamped rows are never stored
+#pragma unroll
+        for (int s0 = 0; s0 < KS; s0 += 4) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(xp + 16 * (s0 + (i >> 1)) + 4 * (i & 1));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float e[8] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w, v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if constexpr (SILU) e[c] = act_fn(e[c], ACT_SILU);
+                    ah[s0 + i][c] = (__bf16)e[c];
+                    if constexpr (X3) al[s0 + i][c] = (__bf16)(e[c] - (float)ah[s0 + i][c]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                // at most eight loads in flight: the fragments need the registers
+        }
+    }
+
+    // ---- copies of column tile j into buffer j & 1, by the four waves of group 1: wave w4 copies k16 steps 4 r + w4
+    const unsigned short* Wh = reinterpret_cast<const unsigned short*>(a.W);
+    const unsigned short* Wl = reinterpret_cast<const unsigned short*>(a.Wlo);
+    auto copy_tile = [&](int j) {
+        unsigned char* dst = smem + (j & 1) * WBUF_B + w4 * 1024;
+        const int64_t src = (int64_t)min(col_tile(j) * 32 + fr, N - 1) * K + 16 * w4 + 8 * fc;
+#pragma unroll
+        for (int r = 0; r < KS / 4; ++r) {
+            dma16_unordered(Wh + src + 64 * r, dst + r * 4096);
+            if constexpr (X3) dma16_unordered(Wl + src + 64 * r, dst + IMG_B + r * 4096);
+        }
+    };
+    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+                     (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
+                     (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
+                     (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+    f32x16 acc;
+    auto finish_tile = [&](int j) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[q];
+        epilogue_patch<1>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
+    };
+
+    if (grp == 1) { copy_tile(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    const bool rows_full = vec && m0 + 32 <= M;
+    for (int j = 0; j < nt; ++j) {
+        const unsigned char* wb = smem + (j & 1) * WBUF_B;
+        // first half: group 0 multiplies tile j; group 1 starts the copies of tile j + 1 (its buffer was last read for tile
+        // j - 1, two barriers ago) and then finishes tile j - 1, so that its stores are YOUNGER than the copies
+        bool counted = false;
+        if (grp == 0) {
+            __builtin_amdgcn_s_setprio(1);
+            rows_mul_tile<X3, KS>(acc, ah, al, wb, lane);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            if (j + 1 < nt) copy_tile(j + 1);
+            if (j > 0) {
+                finish_tile(j - 1);
+                counted = rows_full && (col_tile(j - 1) + 1) * 32 <= N;      // exactly four 16-byte stores per lane
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        // second half: group 1 multiplies tile j, group 0 finishes tile j
+        if (grp == 1) {
+            __builtin_amdgcn_s_setprio(1);
+            rows_mul_tile<X3, KS>(acc, ah, al, wb, lane);
+            __builtin_amdgcn_s_setprio(0);
+            // The copies must have landed before anyone reads them; the stores issued after them need not have (vector
+            // memory operations complete in order, so "at most four outstanding" leaves only those stores in flight).
+            if (counted) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            finish_tile(j);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 1) finish_tile(nt - 1);
+}
+
+template <bool X3, bool SILU, int KS>
+static hipError_t launch_rows3(const LinearArgs& a, hipStream_t stream) {
+    constexpr size_t smem_fixed = 2 * (X3 ? 2 : 1) * (size_t)KS * 1024 + 8 * 32 * EP_LD * sizeof(float);
+    constexpr size_t smem_max = smem_fixed + ROWS_MAX_N * sizeof(float);
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_kernel<X3, SILU, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
+    if (attr != hipSuccess) return attr;
+    const size_t smem = smem_fixed + (size_t)((a.N + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL((linear_rows_kernel<X3, SILU, KS>), dim3((unsigned)((a.M + 255) / 256)), dim3(512), smem, stream, a);
+    return hipGetLastError();
+}
+
+template <bool X3>
+static hipError_t launch_rows(const LinearArgs& a, hipStream_t stream) {
+    const bool silu = a.in_act == ACT_SILU;
+    switch (a.K) {
+        case 256: return silu ? launch_rows3<X3, true, 16>(a, stream) : launch_rows3<X3, false, 16>(a, stream);
+        case 128: return silu ? launch_rows3<X3, true, 8>(a, stream) : launch_rows3<X3, false, 8>(a, stream);
+        case 64: return silu ? launch_rows3<X3, true, 4>(a, stream) : launch_rows3<X3, false, 4>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace
 
 // Shapes the large-tile kernel takes: bf16 operand modes, K a multiple of 64, 16-byte aligned rows, at least two row tiles.
@@ -764,6 +1014,15 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     // LDS-DMA (256x256 tiles).  Measured against the register-staged kernels in one process: 0.8-0.9x their time when there
     // are several rounds of tiles, wide N and long K (M=20480, N=4096, K=1024); equal or slower otherwise (a single column
     // of tiles at N=256: 1.7x slower), so only those shapes take it.
+    // Short K and enough rows for several 256-row workgroups per CU: X stays in registers, W streams through LDS.  Every MFMA
+    // of that kernel reads its W fragment from LDS (1 KB per MFMA, against 0.5 KB in the 64x64 wave tiles), which the LDS
+    // sustains for single-pass bf16 (M=327680 N=1024 K=256: 662 us against 791 us tiled) but not for split operands
+    // (882 against 852 us), so only single-pass bf16 takes it by default.
+    const char* rows_env = getenv("ADX_GEMM_ROWS");             // read per call (tests switch it): 0 never, 1 whenever legal
+    const int rows_mode = rows_env ? atoi(rows_env) : -1;
+    if (force_wm == 0 && rows_mode != 0 && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N &&
+        ((a.M >= 256 * 512 && a.prec == PREC_BF16) || rows_mode == 1))
+        return a.prec == PREC_BF16X3 ? launch_rows<true>(a, stream) : launch_rows<false>(a, stream);
     static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();
     const int64_t tiles_sq = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
     if (!no_glds && force_wm == 0 && tiles_sq >= 900 && a.N >= 1024 && a.K >= 512 && a.xstage &&
