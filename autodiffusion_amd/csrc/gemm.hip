@@ -155,6 +155,8 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
     if (vec) {
         if (n >= a.N) return;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        // column map of Y (groups are multiples of four columns here, so a lane's four columns stay together)
+        const int nc = a.col_group ? (n / a.col_group) * a.col_stride + (n % a.col_group) + a.col_off : n;
         float4 bvec = zero;
         if (bias_reg) bvec = *bias_reg;
         else if (lds_bias) bvec = *reinterpret_cast<const float4*>(lds_bias + n);
@@ -169,7 +171,7 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
                 const int row = (r0 + i) * 8 + (lane >> 3), m = m_base + row;
                 const int mc = m < a.M ? m : a.M - 1;                 // clamped rows are loaded and computed but not stored
                 const int64_t yrow = row_of(a.ymap, mc);
-                yp[i] = m < a.M ? a.Y + yrow * a.ldy + n : nullptr;
+                yp[i] = m < a.M ? a.Y + yrow * a.ldy + nc : nullptr;
                 const float4 raw = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
                 float4 p = zero;
                 if (a.pos) p = *reinterpret_cast<const float4*>(a.pos + (int64_t)((mc % a.pos_period) + a.pos_off) * a.ldp + n);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(c
     // bias / activation / gate / residual code then runs in a ROLLED loop on float4s (small code, 16-byte stores).
     __syncthreads();                                        // every wave is done reading the last K-step
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
-    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+    const bool vec = (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
                      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
                      (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(512, 1) void linear_ws_kernel(const LinearArgs a, i
     }
     __syncthreads();                                              // all consumers are done reading the staging buffers
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
-    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+    const bool vec = (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
                      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
                      (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void linear_glds_kernel(const LinearArgs a,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // every wave is done reading, no copy is in flight
     float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
-    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+    const bool vec = (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
                      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
                      (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
             if constexpr (X3) dma16_unordered(Wl + src + 64 * r, dst + IMG_B + r * 4096);
         }
     };
-    const bool vec = a.col_group == 0 && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
+    const bool vec = (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
                      (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
                      (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
