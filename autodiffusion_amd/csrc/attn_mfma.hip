@@ -12,6 +12,7 @@
 #include "fastmath.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace adx {
 namespace {
@@ -135,7 +136,160 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttentionArgs a) {
     }
 }
 
+// ============================================================================================================
+// The same computation with ONE workgroup per (batch item, head): wave w owns queries 16 w .. 16 w + 15 and all waves share
+// K and V through LDS, so every K / V element is read from memory once (the kernel above reads them once per query tile)
+// and with 16-byte loads.  For head dimensions that are multiples of 32 and Sq == Skv <= 128.
+//   scores: the head dimension advances in chunks of 32: the K chunk (Skv rows x 32 floats) is fetched into registers by all
+//           threads while the previous chunk is multiplied, then written to LDS; Q fragments come straight from memory.
+//   output: V advances in chunks of 32 columns the same way; the probabilities sit in a wave-private LDS patch as above.
+// Image rows are 36 floats: the float4 K-fragment reads (16 rows x one 16-byte column) and the scalar V-fragment reads
+// (keys 4 apart x 16 columns) are both bank-conflict free.  Rows beyond Skv are zero (a zero probability times an
+// undefined V would be NaN).
+// ============================================================================================================
+constexpr int KV_LD = 36;
+
+__global__ __launch_bounds__(512) void attn_mfma_shared_kernel(const AttentionArgs a, int p_ld) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, k4 = lane >> 4;
+    const int nthreads = blockDim.x, n_kt = nthreads >> 6;          // one wave per 16 queries = per key tile
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int S = a.Skv, rows_pad = 16 * n_kt;
+    float* kv = sh;                                                 // rows_pad x KV_LD floats
+    float* Ps = sh + rows_pad * KV_LD + wave * 16 * p_ld;
+    const float* Qb = a.Q + (int64_t)b * a.q_batch_stride + (int64_t)h * a.dh;
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + (int64_t)h * a.dh;
+    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + (int64_t)h * a.dv;
+    const int q0 = 16 * wave;
+
+    // chunk staging: float4 i = tid + nthreads j (j = 0, 1) of the rows_pad x 8 grid: row i >> 3, 16-byte column i & 7
+    int srow[2], scol[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int i = tid + nthreads * j; srow[j] = i >> 3; scol[j] = (i & 7) * 4; }
+    float4 stage[2];
+    auto fetch = [&](const float* base, int64_t ld, int c) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (srow[j] < S) stage[j] = *reinterpret_cast<const float4*>(base + (int64_t)srow[j] * ld + c + scol[j]);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(kv + srow[j] * KV_LD + scol[j]) = stage[j];
+    };
+
+    // ---- scores
+    f32x4 s[MAX_KT];
+#pragma unroll
+    for (int t = 0; t < MAX_KT; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* qrow = Qb + (int64_t)min(q0 + r16, a.Sq - 1) * a.ldq + 4 * k4;
+    fetch(Kb, a.ldk, 0);
+    float4 qn0 = *reinterpret_cast<const float4*>(qrow), qn1 = *reinterpret_cast<const float4*>(qrow + 16);
+    for (int c = 0; c < a.dh; c += 32) {
+        __syncthreads();                                            // everyone is done with the previous image
+        stash();
+        const float4 q0v = qn0, q1v = qn1;
+        __syncthreads();
+        if (c + 32 < a.dh) {
+            fetch(Kb, a.ldk, c + 32);
+            qn0 = *reinterpret_cast<const float4*>(qrow + c + 32);
+            qn1 = *reinterpret_cast<const float4*>(qrow + c + 48);
+        }
+#pragma unroll
+        for (int t = 0; t < MAX_KT; ++t) {
+            if (t < n_kt) {
+                const float4 k0 = *reinterpret_cast<const float4*>(kv + (16 * t + r16) * KV_LD + 4 * k4);
+                const float4 k1 = *reinterpret_cast<const float4*>(kv + (16 * t + r16) * KV_LD + 16 + 4 * k4);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q0v.x, k0.x, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q0v.y, k0.y, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q0v.z, k0.z, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q0v.w, k0.w, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q1v.x, k1.x, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q1v.y, k1.y, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q1v.z, k1.z, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q1v.w, k1.w, s[t], 0, 0, 0);
+            }
+        }
+    }
+    fetch(Vb, a.ldv, 0);                                            // the first V chunk flies under the softmax
+
+    // ---- softmax per query (= per register index and 16-lane row)
+    const float f = a.scale * LOG2E_A;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < MAX_KT; ++t) {
+        if (t < n_kt) {
+            const bool ok = 16 * t + r16 < S;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = ok ? s[t][r] * f : -INFINITY;
+                mx[r] = fmaxf(mx[r], s[t][r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < MAX_KT; ++t) {
+        if (t < n_kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2_fast(s[t][r] - mx[r]);
+                sum[r] += p;
+                Ps[(4 * k4 + r) * p_ld + 16 * t + r16] = p;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum[r] += __shfl_xor(sum[r], o, 64);
+        sum[r] = rcp_fast(sum[r]);
+    }
+
+    // ---- output, 32 columns per V chunk.  MFMA j of key tile t contracts keys 16 t + 4 k + j (k = 0..3 = lane >> 4).
+    for (int c0 = 0; c0 < a.dv; c0 += 32) {
+        __syncthreads();                                            // the previous image is free; the P patch is complete
+        stash();
+        __syncthreads();
+        if (c0 + 32 < a.dv) fetch(Vb, a.ldv, c0 + 32);
+        f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+        for (int t = 0; t < MAX_KT; ++t) {
+            if (t >= n_kt) break;
+            const float4 pv = *reinterpret_cast<const float4*>(&Ps[r16 * p_ld + 16 * t + 4 * k4]);
+            const float* vr = kv + (16 * t + 4 * k4) * KV_LD + r16;
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.x, vr[0], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.x, vr[16], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.y, vr[KV_LD], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.y, vr[KV_LD + 16], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.z, vr[2 * KV_LD], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.z, vr[2 * KV_LD + 16], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.w, vr[3 * KV_LD], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pv.w, vr[3 * KV_LD + 16], o1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + 4 * k4 + r;
+            if (q < a.Sq) {
+                float* orow = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + (int64_t)h * a.dv + c0 + r16;
+                orow[0] = o0[r] * sum[r];
+                orow[16] = o1[r] * sum[r];
+            }
+        }
+    }
+}
+
 }  // namespace
+
+static bool attention_shared_ok(const AttentionArgs& a) {
+    return a.Sq == a.Skv && (a.dh % 32) == 0 && (a.dv % 32) == 0 && (a.ldv % 4) == 0 && (a.v_batch_stride % 4) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.V) & 15) == 0 && a.H <= 65535 && a.B <= 65535;
+}
 
 bool attention_mfma_ok(const AttentionArgs& a) {
     return a.mask_off < 0 && !a.state && !a.key0 && a.Skv <= 16 * MAX_KT && a.dh >= 16 && (a.dh % 16) == 0 && (a.dv % 16) == 0 &&
@@ -145,6 +299,13 @@ bool attention_mfma_ok(const AttentionArgs& a) {
 
 hipError_t attention_mfma(const AttentionArgs& a, hipStream_t stream) {
     if (!attention_mfma_ok(a)) return hipErrorInvalidValue;
+    static const bool no_shared = [] { const char* e = getenv("ADX_ATTN_NO_SHARED"); return e && e[0] == '1'; }();   // measurement switch
+    if (!no_shared && attention_shared_ok(a)) {
+        const int n_kt = (a.Skv + 15) / 16, p_ld = 16 * n_kt + 4;
+        const size_t smem = (size_t)(16 * n_kt * KV_LD + n_kt * 16 * p_ld) * sizeof(float);      // <= 52 KB
+        hipLaunchKernelGGL(attn_mfma_shared_kernel, dim3(a.H, a.B), dim3(64 * n_kt), smem, stream, a, p_ld);
+        return hipGetLastError();
+    }
     dim3 grid((a.Sq + 15) / 16, a.H, a.B);
     if (a.dv >= 64) hipLaunchKernelGGL(attn_mfma_kernel<4>, grid, dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(attn_mfma_kernel<2>, grid, dim3(64), 0, stream, a);

@@ -186,7 +186,9 @@ def test_op_layernorm(dev, d):
 @pytest.mark.parametrize("B,H,Sq,Skv,dh,mask", [(2, 8, 809, 809, 4, -1), (3, 8, 10, 10, 4, 0), (3, 8, 10, 11, 4, 1),
                                                 (2, 8, 11, 949, 4, -1), (2, 4, 80, 80, 16, -1), (2, 8, 80, 80, 32, -1),
                                                 (1, 4, 80, 80, 128, -1), (1, 2, 80, 80, 512, -1), (2, 2, 33, 70, 40, 1), (2, 4, 37, 70, 48, -1),
-                                                (1, 2, 100, 128, 64, -1), (3, 2, 5, 17, 32, -1)])
+                                                (1, 2, 100, 128, 64, -1), (3, 2, 5, 17, 32, -1),
+                                                # one workgroup per (item, head), K / V shared through LDS: ragged and full sequence lengths
+                                                (2, 3, 70, 70, 64, -1), (1, 2, 128, 128, 32, -1), (2, 2, 17, 17, 96, -1), (3, 1, 5, 5, 32, -1)])
 def test_op_attention(dev, B, H, Sq, Skv, dh, mask):
     from autodiffusion_amd import ops
     from oracle import nets
