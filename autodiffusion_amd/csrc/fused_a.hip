@@ -260,6 +260,16 @@ __device__ __forceinline__ void load_row(RowIn& in, const float4* __restrict__ p
     for (int i = 0; i < 5; ++i) in.st[i] = p[64 * (8 + i)];
 }
 
+// Makes the loaded row "used" at this point of the program, so the wait for its loads is placed HERE, in straight-line code,
+// and is counted exactly (everything issued after the loads -- the stores of the tile -- may still be in flight).  Left to
+// the first real use at the top of the tile loop, the wait is merged with the loop-entry state and also covers those stores.
+__device__ __forceinline__ void land_row(RowIn& in) {
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    v4* p = reinterpret_cast<v4*>(&in);
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]),
+                      "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]));
+}
+
 // WAVES = resident wavefronts per SIMD the register budget is set for; a workgroup has 4 waves (WAVES <= 3, three
 // workgroups per CU) or 8 waves (WAVES = 4, two workgroups per CU), so that the LDS copies of the weight image fit.
 template <int PREC, int WAVES>
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
     const int64_t last_tile = (n_rows - 1) >> 5;
     RowIn in;
     load_row(in, a.packed + min((int64_t)wave_global, last_tile) * (PACK_VECS * 64) + lane);
+    land_row(in);
     for (int64_t tile0 = (int64_t)wave_global * 32; tile0 < n_rows; tile0 += (int64_t)n_waves * 32) {
         asm volatile("" ::: "memory");      // keep the per-lane bias / LayerNorm vectors in LDS: hoisting them costs ~100 registers
         const int64_t row = min(tile0 + c, n_rows - 1);          // clamp: out-of-range lanes recompute the last row, never store
@@ -393,19 +404,20 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
                 }
             }
         }
-#pragma unroll 1
+        // Lanes past the last row hold a copy of it (the packed tile repeats it) and store the same values to the same
+        // place: the stores are unconditional, so exactly eight vector-memory operations follow the loads of the next tile.
+#pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const f32x16 kv = mm<PREC>(img, tile_base(3) + nt, gn, zero16(), lane);
-            if (live) {
-                float* op = a.kv + row * a.ldkv + 32 * nt;
+            float* op = a.kv + row * a.ldkv + 32 * nt;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 b = *reinterpret_cast<const float4*>(bkv + 32 * nt + 8 * g + 4 * h);
-                    *reinterpret_cast<float4*>(op + 8 * g + 4 * h) =
-                        make_float4(kv[4 * g] + b.x, kv[4 * g + 1] + b.y, kv[4 * g + 2] + b.z, kv[4 * g + 3] + b.w);
-                }
+            for (int g = 0; g < 4; ++g) {
+                const float4 b = *reinterpret_cast<const float4*>(bkv + 32 * nt + 8 * g + 4 * h);
+                *reinterpret_cast<float4*>(op + 8 * g + 4 * h) =
+                    make_float4(kv[4 * g] + b.x, kv[4 * g + 1] + b.y, kv[4 * g + 2] + b.z, kv[4 * g + 3] + b.w);
             }
         }
+        land_row(in);
     }
 }
 
