@@ -1013,21 +1013,22 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + TN - 1) / TN);
     const bool tall = force_wm ? force_wm >= 4 : tiles256 >= 512;
     // With a staging buffer from the caller both operands are re-laid as K-blocked bf16 planes once and the tiles are filled by
-    // LDS-DMA (256x256 tiles).  Measured against the register-staged kernels in one process: 0.8-0.9x their time when there
-    // are several rounds of tiles, wide N and long K (M=20480, N=4096, K=1024); equal or slower otherwise (a single column
-    // of tiles at N=256: 1.7x slower), so only those shapes take it.
-    // Short K and enough rows for several 256-row workgroups per CU: X stays in registers, W streams through LDS.  Every MFMA
-    // of that kernel reads its W fragment from LDS (1 KB per MFMA, against 0.5 KB in the 64x64 wave tiles), which the LDS
-    // sustains for single-pass bf16 (M=327680 N=1024 K=256: 662 us against 791 us tiled) but not for split operands
-    // (882 against 852 us), so only single-pass bf16 takes it by default.
+    // LDS-DMA (256x256 tiles).  Measured against the register-staged kernels with the two alternating in one process
+    // (M=20480 N=4096 K=1024): 0.70x their time for single-pass bf16, 0.96x for split operands; M=163840 N=2048 K=256 split:
+    // 0.91x; equal at N <= 1536 with K=256; slower with few tiles (M=5120: 1.27x) or a single column of 256-wide tiles.
+    // Short K and enough rows for four or more rounds of 256-row workgroups: X stays in registers, W streams through LDS.
+    // Measured against the tiled kernels with the two alternating on one box (M=327680, K=256): single-pass bf16 N=1024
+    // 609 against 755 us, N=1536 864 against 1047; split operands N=1024 752 against 820, N=1536 1076 against 1154, N=768 576
+    // against 605; slower at N=256 (269 against 245) and with 2.5 rounds or fewer (M=163840 N=1024: 446 against 422).
     const char* rows_env = getenv("ADX_GEMM_ROWS");             // read per call (tests switch it): 0 never, 1 whenever legal
     const int rows_mode = rows_env ? atoi(rows_env) : -1;
     if (force_wm == 0 && rows_mode != 0 && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N &&
-        ((a.M >= 256 * 512 && a.prec == PREC_BF16) || rows_mode == 1))
+        ((a.M >= 256 * 1024 && a.N >= (a.prec == PREC_BF16 ? 512 : 768)) || rows_mode == 1))
         return a.prec == PREC_BF16X3 ? launch_rows<true>(a, stream) : launch_rows<false>(a, stream);
     static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();
     const int64_t tiles_sq = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    if (!no_glds && force_wm == 0 && tiles_sq >= 900 && a.N >= 1024 && a.K >= 512 && a.xstage &&
+    static const bool glds_any = [] { const char* e = getenv("ADX_GEMM_DMA_ANY"); return e && e[0] == '1'; }();     // measurement switch
+    if (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any) && a.xstage &&
         a.xstage_bytes >= linear_stage_bytes(a.M, a.Wblk ? 0 : a.N, a.K, a.prec) && (reinterpret_cast<uintptr_t>(a.xstage) & 15) == 0 &&
         (int64_t)a.M * a.K < ((int64_t)1 << 31) && (int64_t)a.N * a.K < ((int64_t)1 << 31))
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);

@@ -109,7 +109,7 @@ def test_op_linear_staged(dev, M, N, K, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
-@pytest.mark.parametrize("M,N,K", [(131072 + 77, 200, 256), (131072, 70, 128), (140000, 96, 64)])
+@pytest.mark.parametrize("M,N,K", [(262144 + 77, 776, 256), (131072, 70, 128), (140000, 96, 64)])
 def test_op_linear_row_stationary(dev, M, N, K, prec):
     """Short K and many rows take the row-stationary kernel (X fragments in registers, W streamed through LDS): ragged M,
     N not a multiple of the 32-column tile, and N not a multiple of 4 (scalar epilogue), against fp64."""
@@ -118,16 +118,23 @@ def test_op_linear_row_stationary(dev, M, N, K, prec):
     x = torch.randn(M, K, generator=g).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)
-    y = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec)
-    xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if prec == "bf16" else (x.double(), w.double())
-    ref = torch.nn.functional.gelu(xr @ wr.T + b.double(), approximate="tanh").float()
-    assert rel_err(y.cpu(), ref.cpu()) < 2e-5
-    os.environ["ADX_GEMM_ROWS"] = "0"          # the tiled kernels on the same inputs: same products, different summation order
-    try:
-        y0 = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec)
-    finally:
-        del os.environ["ADX_GEMM_ROWS"]
-    assert rel_err(y.cpu(), y0.cpu()) < 2e-5
+    ys = {}
+    for mode in ("1", "0", None):       # forced, forbidden (the tiled kernels: same products, different summation order), default
+        if mode is not None:
+            os.environ["ADX_GEMM_ROWS"] = mode
+        try:
+            ys[mode] = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec)
+        finally:
+            os.environ.pop("ADX_GEMM_ROWS", None)
+    ref = torch.zeros_like(ys["1"])
+    for i in range(0, M, 65536):        # fp64 reference in slices (the full fp64 product would take gigabytes)
+        xs = x[i:i + 65536]
+        xr, wr = (xs.bfloat16().double(), w.bfloat16().double()) if prec == "bf16" else (xs.double(), w.double())
+        ref[i:i + 65536] = torch.nn.functional.gelu(xr @ wr.T + b.double(), approximate="tanh").float()
+    for mode, y in ys.items():              # same measure as rel_err, evaluated on the device (800 MB per tensor)
+        assert float((y - ref).abs().max() / ref.abs().max()) < 2e-5, mode
+    # (both kernels add the same products in the same order along K, so their results may be bit-identical: the values
+    # cannot tell which kernel ran)
 
 
 @pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
