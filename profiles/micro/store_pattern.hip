@@ -1,6 +1,9 @@
 // Micro-benchmark: HBM store bandwidth of a 256x128-float tile epilogue, by store pattern.
 //   pattern 0: dword stores, 32 lanes x 4 B per row segment (MFMA accumulator layout)
 //   pattern 1: float4 stores, 32 lanes x 16 B = one 512-B tile row per half-wave
+//   pattern 2: float4 stores of the 32x32 epilogue patches: 8 lanes x 16 B = a 128-B row segment, 8 rows per instruction
+//   pattern 3: pattern 2 walked like the row-stationary GEMM: a workgroup owns 256 rows and visits all N/32 column tiles
+// usage: store_pattern [N [M]]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +18,23 @@ __global__ __launch_bounds__(512) void store_kernel(float* Y, int M, int N, int 
                 const int m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fc;
                 for (int j = 0; j < 2; ++j) Y[(int64_t)m * N + n0 + wc * 64 + j * 32 + fr] = (float)(m + j);
             }
+    } else if (pattern == 2) {
+        for (int t = 0; t < 4; ++t)
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = m0 + wr * 64 + (t >> 1) * 32 + rr * 8 + (lane >> 3);
+                *reinterpret_cast<float4*>(Y + (int64_t)m * N + n0 + wc * 64 + (t & 1) * 32 + (lane & 7) * 4) = make_float4((float)m, 1.f, 2.f, 3.f);
+            }
+    } else if (pattern == 3) {
+        const int nt = N / 32;
+        if (tile >= M / 256) return;
+        const int jrot = (tile * 7) % nt;
+        for (int j = 0; j < nt; ++j) {
+            const int c = (j + jrot) % nt;
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = tile * 256 + wave * 32 + rr * 8 + (lane >> 3);
+                *reinterpret_cast<float4*>(Y + (int64_t)m * N + c * 32 + (lane & 7) * 4) = make_float4((float)m, 1.f, 2.f, 3.f);
+            }
+        }
     } else {
         // wave w writes rows w*32 .. w*32+31 of the tile, two rows (2 x 512 B) per instruction
         for (int r = 0; r < 16; ++r) {
@@ -25,13 +45,13 @@ __global__ __launch_bounds__(512) void store_kernel(float* Y, int M, int N, int 
 }
 
 int main(int argc, char** argv) {
-    const int M = 20480, N = argc > 1 ? atoi(argv[1]) : 4096;
+    const int N = argc > 1 ? atoi(argv[1]) : 4096, M = argc > 2 ? atoi(argv[2]) : 20480;
     float* Y;
     hipMalloc(&Y, (size_t)M * N * 4);
     const int tiles_n = N / 128, tiles = (M / 256) * tiles_n;
     hipEvent_t s, e;
     hipEventCreate(&s); hipEventCreate(&e);
-    for (int pattern = 0; pattern < 2; ++pattern) {
+    for (int pattern = 0; pattern < 4; ++pattern) {
         for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(store_kernel, dim3(tiles), dim3(512), 0, 0, Y, M, N, tiles_n, pattern);
         hipEventRecord(s);
         for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(store_kernel, dim3(tiles), dim3(512), 0, 0, Y, M, N, tiles_n, pattern);
