@@ -16,6 +16,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace adx {
 namespace {
 
@@ -141,46 +143,39 @@ __device__ __forceinline__ void act_patch(float (&v)[RP][4], int act) {
 #undef ADX_ACT_ALL
 }
 
-// Y rows m_base .. m_base+31, columns n_base .. n_base+31 from a 32x32 patch of raw accumulators in LDS.
-// Vector form: a lane owns four columns of rows (lane >> 3) + 8 rr, handled RP rows at a time.  Every load of a pass
-// (position table, gate, residual) is issued before its first store and the stores go out back to back: vector-memory
-// operations retire in order, so a load issued after a store waits for that store to complete.  With RP = 4 nothing in
-// a patch waits for a store; RP = 2 halves the registers and waits once per patch when there is a gate or a residual.
-// lds_bias: the bias vector (zeros without one) in LDS; bias_reg: this lane's four bias values, fetched by the caller before
-// its first patch -- either keeps the bias load (which would wait for the stores of the previous patch) out of the patch.
-template <int RP>
-__device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float* ep, int m_base, int n_base, int lane, bool vec,
-                                               const float* lds_bias = nullptr, const float4* bias_reg = nullptr) {
-    const int c4 = (lane & 7) * 4, n = n_base + c4;
-    if (vec) {
-        if (n >= a.N) return;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-        // column map of Y (groups are multiples of four columns here, so a lane's four columns stay together)
-        const int nc = a.col_group ? (n / a.col_group) * a.col_stride + (n % a.col_group) + a.col_off : n;
-        float4 bvec = zero;
-        if (bias_reg) bvec = *bias_reg;
-        else if (lds_bias) bvec = *reinterpret_cast<const float4*>(lds_bias + n);
-        else if (a.bias) bvec = *reinterpret_cast<const float4*>(a.bias + n);
+// Vector form of the epilogue of one 32x32 patch: a lane owns four columns of rows (lane >> 3) + 8 rr, handled RP rows at a
+// time.  Every load of a pass (position table, gate, residual) is issued before its first store and the stores go out back
+// to back: vector-memory operations retire in order, so a load issued after a store waits for that store to complete.
+// EXTRA = false is the instance for calls without position table, gate and residual: it contains no vector-memory load at
+// all, so no wait at all (where the optional loads sit under branches the compiler emits one unconditional wait for
+// everything in flight after them -- the previous patch's stores included -- whether or not a load was issued).
+template <int RP, bool EXTRA>
+__device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* ep, int m_base, int n, int nc, int lane, float4 bvec) {
+    const int c4 = (lane & 7) * 4;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int r0 = 0; r0 < 4; r0 += RP) {
-            float v[RP][4];
-            float4 g[RP], r[RP];
-            float* yp[RP];
+    for (int r0 = 0; r0 < 4; r0 += RP) {
+        float v[RP][4];
+        float4 g[RP], r[RP];
+        float* yp[RP];
 #pragma unroll
-            for (int i = 0; i < RP; ++i) {
-                const int row = (r0 + i) * 8 + (lane >> 3), m = m_base + row;
-                const int mc = m < a.M ? m : a.M - 1;                 // clamped rows are loaded and computed but not stored
-                const int64_t yrow = row_of(a.ymap, mc);
-                yp[i] = m < a.M ? a.Y + yrow * a.ldy + nc : nullptr;
-                const float4 raw = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
-                float4 p = zero;
+        for (int i = 0; i < RP; ++i) {
+            const int row = (r0 + i) * 8 + (lane >> 3), m = m_base + row;
+            const int mc = m < a.M ? m : a.M - 1;                 // clamped rows are loaded and computed but not stored
+            const int64_t yrow = row_of(a.ymap, mc);
+            yp[i] = m < a.M ? a.Y + yrow * a.ldy + nc : nullptr;
+            const float4 raw = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
+            float4 p = zero;
+            g[i] = zero; r[i] = zero;
+            if constexpr (EXTRA) {
                 if (a.pos) p = *reinterpret_cast<const float4*>(a.pos + (int64_t)((mc % a.pos_period) + a.pos_off) * a.ldp + n);
-                g[i] = zero; r[i] = zero;
                 if (a.gate) g[i] = *reinterpret_cast<const float4*>(a.gate + yrow * a.ldg + n);
                 if (a.res) r[i] = *reinterpret_cast<const float4*>(a.res + yrow * a.ldr + n);
-                v[i][0] = raw.x + bvec.x + p.x; v[i][1] = raw.y + bvec.y + p.y; v[i][2] = raw.z + bvec.z + p.z; v[i][3] = raw.w + bvec.w + p.w;
             }
-            act_patch<RP>(v, a.act);
+            v[i][0] = raw.x + bvec.x + p.x; v[i][1] = raw.y + bvec.y + p.y; v[i][2] = raw.z + bvec.z + p.z; v[i][3] = raw.w + bvec.w + p.w;
+        }
+        act_patch<RP>(v, a.act);
+        if constexpr (EXTRA) {
             if (a.gate) {
 #pragma unroll
                 for (int i = 0; i < RP; ++i) { v[i][0] *= g[i].x; v[i][1] *= g[i].y; v[i][2] *= g[i].z; v[i][3] *= g[i].w; }
@@ -189,10 +184,32 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
 #pragma unroll
                 for (int i = 0; i < RP; ++i) { v[i][0] += r[i].x; v[i][1] += r[i].y; v[i][2] += r[i].z; v[i][3] += r[i].w; }
             }
-#pragma unroll
-            for (int i = 0; i < RP; ++i)
-                if (yp[i]) *reinterpret_cast<float4*>(yp[i]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
         }
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+            if (yp[i]) *reinterpret_cast<float4*>(yp[i]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+    }
+}
+
+// Y rows m_base .. m_base+31, columns n_base .. n_base+31 from a 32x32 patch of raw accumulators in LDS.
+// lds_bias: the bias vector (zeros without one) in LDS; bias_reg: this lane's four bias values, fetched by the caller before
+// its first patch -- either keeps the bias load (which would wait for the stores of the previous patch) out of the patch.
+// With RP = 4 nothing in a patch waits for a store of the same patch; RP = 1 needs the fewest registers.
+// EXTRA: the call has a position table, gate or residual (the caller tests that once, outside its loop over patches, so that
+// each loop body holds one instance of this code and still unrolls: the accumulators are indexed by the loop counter).
+template <int RP, bool EXTRA>
+__device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float* ep, int m_base, int n_base, int lane, bool vec,
+                                               const float* lds_bias = nullptr, const float4* bias_reg = nullptr) {
+    const int c4 = (lane & 7) * 4, n = n_base + c4;
+    if (vec) {
+        if (n >= a.N) return;
+        // column map of Y (groups are multiples of four columns here, so a lane's four columns stay together)
+        const int nc = a.col_group ? (n / a.col_group) * a.col_stride + (n % a.col_group) + a.col_off : n;
+        float4 bvec = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias_reg) bvec = *bias_reg;
+        else if (lds_bias) bvec = *reinterpret_cast<const float4*>(lds_bias + n);
+        else if (a.bias) bvec = *reinterpret_cast<const float4*>(a.bias + n);
+        epilogue_rows<RP, EXTRA>(a, ep, m_base, n, nc, lane, bvec);
         return;
     }
 #pragma unroll 1
@@ -361,13 +378,16 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(c
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
+    auto patches = [&](auto extra) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int i = t >> 1, j = t & 1;
+        for (int t = 0; t < 4; ++t) {
+            const int i = t >> 1, j = t & 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
-        epilogue_patch<4>(a, ep, m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
-    }
+            for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
+            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+        }
+    };
+    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
 }
 
 // ============================================================================================================
@@ -507,13 +527,16 @@ __global__ __launch_bounds__(512, 1) void linear_ws_kernel(const LinearArgs a, i
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
+    auto patches = [&](auto extra) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int i = t >> 1, j = t & 1;
+        for (int t = 0; t < 8; ++t) {
+            const int i = t >> 1, j = t & 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
-        epilogue_patch<4>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
-    }
+            for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
+            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+        }
+    };
+    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
 }
 
 template <bool X3, bool SILU>
@@ -714,13 +737,16 @@ __global__ __launch_bounds__(512, 1) void linear_glds_kernel(const LinearArgs a,
     }
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
+    auto patches = [&](auto extra) {
 #pragma unroll
-    for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
-        const int i = t >> 1, j = t & 1;
+        for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
+            const int i = t >> 1, j = t & 1;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
-        epilogue_patch<4>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
-    }
+            for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
+            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+        }
+    };
+    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
 }
 
 // X (fp32, row map, optional SiLU) -> K-blocked bf16 planes [K/16][M][16]: high halves and, when lo != nullptr,
@@ -817,7 +843,7 @@ __device__ __forceinline__ void rows_mul_tile(f32x16& acc, const bf16x8 (&ah)[KS
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     // W fragments run two k16 steps ahead of the MFMAs (three register sets): an LDS read takes longer than the three
     // MFMAs of a step, and the scheduler left to itself reads each step right before it is used.
-    constexpr int AHEAD = 2;
+    constexpr int AHEAD = 4;
     bf16x8 bh[AHEAD + 1], bl[X3 ? AHEAD + 1 : 1];
     auto read = [&](int s) {
         bh[s % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(wb + (s * 64 + lane) * 16);
@@ -899,10 +925,12 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
                      (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
     f32x16 acc;
+    const bool extra = a.pos || a.gate || a.res;
     auto finish_tile = [&](int j) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[q];
-        epilogue_patch<1>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
+        if (extra) epilogue_patch<1, true>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
+        else epilogue_patch<1, false>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
     };
 
     if (grp == 1) { copy_tile(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -914,13 +942,13 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
         // j - 1, two barriers ago) and then finishes tile j - 1, so that its stores are YOUNGER than the copies
         bool counted = false;
         if (grp == 0) {
-            __builtin_amdgcn_s_setprio(1);
             rows_mul_tile<X3, KS>(acc, ah, al, wb, lane);
-            __builtin_amdgcn_s_setprio(0);
         } else {
             if (j + 1 < nt) copy_tile(j + 1);
             if (j > 0) {
+                __builtin_amdgcn_s_setprio(2);
                 finish_tile(j - 1);
+                __builtin_amdgcn_s_setprio(0);
                 counted = rows_full && (col_tile(j - 1) + 1) * 32 <= N;      // exactly four 16-byte stores per lane
             }
         }
@@ -928,15 +956,15 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
         __builtin_amdgcn_s_barrier();
         // second half: group 1 multiplies tile j, group 0 finishes tile j
         if (grp == 1) {
-            __builtin_amdgcn_s_setprio(1);
             rows_mul_tile<X3, KS>(acc, ah, al, wb, lane);
-            __builtin_amdgcn_s_setprio(0);
             // The copies must have landed before anyone reads them; the stores issued after them need not have (vector
             // memory operations complete in order, so "at most four outstanding" leaves only those stores in flight).
             if (counted) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
+            __builtin_amdgcn_s_setprio(2);
             finish_tile(j);
+            __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
