@@ -930,7 +930,7 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
 #pragma unroll
         for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[q];
         if (extra) epilogue_patch<1, true>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
-        else epilogue_patch<1, false>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
+        else epilogue_patch<2, false>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
     };
 
     if (grp == 1) { copy_tile(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
