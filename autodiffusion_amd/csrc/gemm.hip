@@ -865,7 +865,9 @@ __device__ __forceinline__ void rows_mul_tile(f32x16& acc, const bf16x8 (&ah)[KS
     }
 }
 
-template <bool X3, bool SILU, int KS>
+// EXTRA: the call has a position table, gate or residual.  The launcher only takes calls whose epilogue can use 16-byte
+// accesses (linear_vec_ok), so the kernel holds exactly one epilogue variant.
+template <bool X3, bool SILU, int KS, bool EXTRA>
 __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a) {
     constexpr int IMG_B = KS * 1024;                          // one operand image of a 32-column tile
     constexpr int WBUF_B = (X3 ? 2 : 1) * IMG_B;
@@ -919,18 +921,12 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
             if constexpr (X3) dma16_unordered(Wl + src + 64 * r, dst + IMG_B + r * 4096);
         }
     };
-    const bool vec = (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (N & 3) == 0 && (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 &&
-                     (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
-                     (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
-                     (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
-                     (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+    constexpr bool vec = true;
     f32x16 acc;
-    const bool extra = a.pos || a.gate || a.res;
     auto finish_tile = [&](int j) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[q];
-        if (extra) epilogue_patch<1, true>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
-        else epilogue_patch<2, false>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
+        epilogue_patch<EXTRA ? 1 : (X3 ? 2 : 4), EXTRA>(a, ep, m0, col_tile(j) * 32, lane, vec, lbias);
     };
 
     if (grp == 1) { copy_tile(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -972,16 +968,21 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
     if (grp == 1) finish_tile(nt - 1);
 }
 
-template <bool X3, bool SILU, int KS>
-static hipError_t launch_rows3(const LinearArgs& a, hipStream_t stream) {
+template <bool X3, bool SILU, int KS, bool EXTRA>
+static hipError_t launch_rows4(const LinearArgs& a, hipStream_t stream) {
     constexpr size_t smem_fixed = 2 * (X3 ? 2 : 1) * (size_t)KS * 1024 + 8 * 32 * EP_LD * sizeof(float);
     constexpr size_t smem_max = smem_fixed + ROWS_MAX_N * sizeof(float);
-    static const hipError_t attr =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_kernel<X3, SILU, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_rows_kernel<X3, SILU, KS, EXTRA>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_max);
     if (attr != hipSuccess) return attr;
     const size_t smem = smem_fixed + (size_t)((a.N + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL((linear_rows_kernel<X3, SILU, KS>), dim3((unsigned)((a.M + 255) / 256)), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((linear_rows_kernel<X3, SILU, KS, EXTRA>), dim3((unsigned)((a.M + 255) / 256)), dim3(512), smem, stream, a);
     return hipGetLastError();
+}
+
+template <bool X3, bool SILU, int KS>
+static hipError_t launch_rows3(const LinearArgs& a, hipStream_t stream) {
+    return (a.pos || a.gate || a.res) ? launch_rows4<X3, SILU, KS, true>(a, stream) : launch_rows4<X3, SILU, KS, false>(a, stream);
 }
 
 template <bool X3>
@@ -993,6 +994,15 @@ static hipError_t launch_rows(const LinearArgs& a, hipStream_t stream) {
         case 64: return silu ? launch_rows3<X3, true, 4>(a, stream) : launch_rows3<X3, false, 4>(a, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+// The epilogue of this call can use 16-byte accesses for every operand (the same test the kernels make for themselves).
+static bool linear_vec_ok(const LinearArgs& a) {
+    return (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (a.N & 3) == 0 && (a.ldy & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+           (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
+           (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
+           (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
 }
 
 }  // namespace
@@ -1050,7 +1060,7 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     // against 605; slower at N=256 (269 against 245) and with 2.5 rounds or fewer (M=163840 N=1024: 446 against 422).
     const char* rows_env = getenv("ADX_GEMM_ROWS");             // read per call (tests switch it): 0 never, 1 whenever legal
     const int rows_mode = rows_env ? atoi(rows_env) : -1;
-    if (force_wm == 0 && rows_mode != 0 && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N &&
+    if (force_wm == 0 && rows_mode != 0 && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N && linear_vec_ok(a) &&
         ((a.M >= 256 * 1024 && a.N >= (a.prec == PREC_BF16 ? 512 : 768)) || rows_mode == 1))
         return a.prec == PREC_BF16X3 ? launch_rows<true>(a, stream) : launch_rows<false>(a, stream);
     static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();

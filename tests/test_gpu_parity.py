@@ -111,8 +111,9 @@ def test_op_linear_staged(dev, M, N, K, prec):
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("M,N,K", [(262144 + 77, 776, 256), (131072, 70, 128), (140000, 96, 64)])
 def test_op_linear_row_stationary(dev, M, N, K, prec):
-    """Short K and many rows take the row-stationary kernel (X fragments in registers, W streamed through LDS): ragged M,
-    N not a multiple of the 32-column tile, and N not a multiple of 4 (scalar epilogue), against fp64."""
+    """Short K and many rows take the row-stationary kernel (X fragments in registers, W streamed through LDS): ragged M and
+    N not a multiple of the 32-column tile; N not a multiple of 4 (no 16-byte epilogue) must fall back to the tiled kernels even
+    when the row-stationary one is forced.  Against fp64."""
     from autodiffusion_amd import _lib, ops
     g = torch.Generator().manual_seed(M + 3 * N + K)
     x = torch.randn(M, K, generator=g).to(dev)
