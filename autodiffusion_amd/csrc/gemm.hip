@@ -942,9 +942,7 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
         } else {
             if (j + 1 < nt) copy_tile(j + 1);
             if (j > 0) {
-                __builtin_amdgcn_s_setprio(2);
                 finish_tile(j - 1);
-                __builtin_amdgcn_s_setprio(0);
                 counted = rows_full && (col_tile(j - 1) + 1) * 32 <= N;      // exactly four 16-byte stores per lane
             }
         }
@@ -958,9 +956,7 @@ __global__ __launch_bounds__(512, 1) void linear_rows_kernel(const LinearArgs a)
             if (counted) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            __builtin_amdgcn_s_setprio(2);
             finish_tile(j);
-            __builtin_amdgcn_s_setprio(0);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
