@@ -1050,14 +1050,14 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     // LDS-DMA (256x256 tiles).  Measured against the register-staged kernels with the two alternating in one process
     // (M=20480 N=4096 K=1024): 0.70x their time for single-pass bf16, 0.96x for split operands; M=163840 N=2048 K=256 split:
     // 0.91x; equal at N <= 1536 with K=256; slower with few tiles (M=5120: 1.27x) or a single column of 256-wide tiles.
-    // Short K and enough rows for four or more rounds of 256-row workgroups: X stays in registers, W streams through LDS.
-    // Measured against the tiled kernels with the two alternating on one box (M=327680, K=256): single-pass bf16 N=1024
-    // 609 against 755 us, N=1536 864 against 1047; split operands N=1024 752 against 820, N=1536 1076 against 1154, N=768 576
-    // against 605; slower at N=256 (269 against 245) and with 2.5 rounds or fewer (M=163840 N=1024: 446 against 422).
+    // Short K and enough rows for 2.5 or more rounds of 256-row workgroups: X stays in registers, W streams through LDS.
+    // Measured against the tiled kernels with the two alternating on one box (K=256, split operands): M=327680 N=1024 632
+    // against 820 us, N=1536 915 against 1154, N=768 501 against 593, N=512 387 against 423; M=163840 N=1024 376 against 429,
+    // N=1536 523 against 591; single-pass bf16 M=327680 N=1024 404 against 755.  Slower at N=256 (241 against 228).
     const char* rows_env = getenv("ADX_GEMM_ROWS");             // read per call (tests switch it): 0 never, 1 whenever legal
     const int rows_mode = rows_env ? atoi(rows_env) : -1;
     if (force_wm == 0 && rows_mode != 0 && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N && linear_vec_ok(a) &&
-        ((a.M >= 256 * 1024 && a.N >= (a.prec == PREC_BF16 ? 512 : 768)) || rows_mode == 1))
+        ((a.M >= 160 * 1024 && a.N >= 512) || rows_mode == 1))
         return a.prec == PREC_BF16X3 ? launch_rows<true>(a, stream) : launch_rows<false>(a, stream);
     static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();
     const int64_t tiles_sq = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
