@@ -315,6 +315,11 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
                 att[4 * g] = t.x; att[4 * g + 1] = t.y; att[4 * g + 2] = t.z; att[4 * g + 3] = t.w;
                 in.x[g] = *reinterpret_cast<const float4*>(a.x0_time + 8 * g + 4 * h);
             }
+            // These loads run in 1 tile of 25.  Their wait must sit INSIDE this branch: placed at the first use after the
+            // branch it would run on every tile and, with nothing loaded, wait for the previous tile's stores instead.
+            typedef __attribute__((ext_vector_type(4))) float v4;
+            v4* xp = reinterpret_cast<v4*>(in.x);
+            asm volatile("" : "+v"(att), "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]));
         } else {
             const float* stf = reinterpret_cast<const float*>(in.st);
 #pragma unroll
