@@ -243,6 +243,19 @@ hipError_t select_modes(const SelectModesArgs& a, hipStream_t stream);
 // Per-scenario ADE / FDE / heading errors / max displacement; out[B][18], layout in metrics.hip.  S divides 80, C in {2, 4}.
 hipError_t trajectory_metrics(const float* pred, const float* label, int B, int S, int C, float* out, hipStream_t stream);
 
+// Device-side Gaussian noise (extras.hip).  ctl_dev = {seed, global index of batch row 0}; out[n_lead][B][row_len], the value
+// of an element depends only on (seed, global row, leading index, element / 4): Philox4x32-10 + Box-Muller.
+hipError_t set_noise_ctl(uint64_t* ctl_dev, uint64_t seed, uint64_t row0, hipStream_t stream);
+hipError_t randn_rows(const uint64_t* ctl_dev, float* out, int n_lead, int B, int row_len, hipStream_t stream);
+
+// Forward diffusion of n_rows rows of row_len values with a timestep per row: xt = sqrt_acp[t] x0 + sqrt_1m_acp[t] noise;
+// v (optional) = sqrt_acp[t] noise - sqrt_1m_acp[t] x0.
+hipError_t q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* xt,
+                    float* v, int n_rows, int row_len, hipStream_t stream);
+// loss_rows[b] = weight[t[b]] * mean((out[b] - target[b])^2); loss_mean (optional) = mean over rows.
+hipError_t weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows, float* loss_mean,
+                        int n_rows, int row_len, hipStream_t stream);
+
 // f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);
 // strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)

@@ -74,11 +74,35 @@ struct adx_engine {
     // graphs
     hipStream_t cap_stream = nullptr;
     std::map<std::string, hipGraphExec_t> graphs;
+    int64_t n_captures = 0;              // graphs captured since the engine was created (adx_engine_capture_count)
+
+    // Callers that hand in the same buffers on every call get a graph keyed on those pointers.  A caller whose pointers
+    // change between calls of the same shape (fresh tensors per batch) is switched to STAGED mode for that shape: its
+    // inputs are copied into engine-owned buffers on the call's stream, ONE graph captured on those buffers is replayed,
+    // and the result is copied out -- so the capture happens once, not per call.
+    struct IoMode { std::string ptr_key; bool staged = false; };
+    std::map<std::string, IoMode> io_modes;
+    char* stage_buf = nullptr;
+    size_t stage_bytes = 0;
+    int ensure_stage(size_t bytes);       // (re)allocates stage_buf; never inside a capture
+    // decides the mode of this call; returns true when the call must go through the staging buffers
+    bool use_staging(const std::string& shape_key, const std::string& ptr_key, unsigned flags);
+
+    // device-side noise for callers that pass none: {seed, global row of batch row 0} in device memory (read by the
+    // generator kernel inside the graph, rewritten before every launch), and the buffer the generator fills
+    uint64_t noise_seed = 0, noise_row0 = 0;
+    uint64_t* noise_ctl = nullptr;
+    float* noise_buf = nullptr;
+    size_t noise_bytes = 0;
+    int ensure_noise(size_t bytes);
+    int push_noise_ctl(hipStream_t s);    // enqueue the current seed / row offset
+    int n_schedule_draws() const;         // noise tensors the schedule reads after the initial one
 
     virtual ~adx_engine();
     virtual std::vector<adx::ParamSpec> expected_params() const = 0;
     virtual int carve_workspace(int max_batch, bool dry_run, size_t* bytes) = 0;
-    virtual int build_time_table(hipStream_t s) = 0;   // fills temb_table for the current schedule
+    virtual int build_time_table(hipStream_t s) = 0;   // fills temb_table and every weight-derived table for the current schedule
+    virtual void on_workspace_realloc() {}             // caches that live in the workspace are gone
 
     int set_tensor(const char* name, const float* data, const int64_t* shape, int ndim);
     int finalize();
@@ -123,6 +147,7 @@ int adx_engine::run(const std::string& key, unsigned flags, hipStream_t stream, 
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) return adx::hip_fail(e, "hipGraphInstantiate");
+        ++n_captures;
         it = graphs.emplace(key, exec).first;
     }
     ADX_HIP(hipGraphLaunch(it->second, stream));

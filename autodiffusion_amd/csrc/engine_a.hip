@@ -76,6 +76,8 @@ struct EngineA final : adx_engine {
         if (tailm_vecs) (void)hipFree(tailm_vecs);
     }
 
+    void on_workspace_realloc() override { maps_batch = -1; }     // the map embedding and its caches lived in the old workspace
+
     explicit EngineA(const adx_model_config& c) {
         cfg = c;
         d = c.d_model; H = c.n_head; T = c.horizon; NP = c.n_prior_tokens; Cin = c.in_dim; Cout = c.out_dim; Cp = c.prior_dim;
@@ -702,23 +704,66 @@ struct EngineA final : adx_engine {
         return ADX_OK;
     }
 
+    // Noise for a call that passes none: [n_lead][1 + draws][B][T * Cin], filled by the generator kernel inside the graph.
+    int device_noise(int n_lead, int B, const float** noise, int* n_noise) {
+        *n_noise = 1 + n_schedule_draws();
+        ADX_TRY(ensure_noise(sizeof(float) * (size_t)n_lead * *n_noise * B * T * Cin));
+        *noise = noise_buf;
+        return ADX_OK;
+    }
+
+    // Bump carving of the staging buffer (256-byte slots); `take` returns the offset of a slot of `bytes` bytes.
+    struct StagePlan {
+        size_t total = 0;
+        size_t take(size_t bytes) { const size_t o = total; total += (bytes + 255) / 256 * 256; return o; }
+    };
+
     int sample(int B, const float* maps, const float* tran, const float* prior, const float* noise, int n_noise, float* out,
                float* trace_x, float* trace_out, unsigned flags, hipStream_t s) {
         ADX_TRY(check_ready(B, "sample_a"));
         ADX_TRY(validate_sampling(n_noise, "sample_a"));
-        char key[256];
-        snprintf(key, sizeof key, "s|%d|%p|%p|%p|%p|%d|%p|%p|%p|%u|%d", B, (const void*)maps, (const void*)tran, (const void*)prior,
-                 (const void*)noise, n_noise, (void*)out, (void*)trace_x, (void*)trace_out, flags, schedule_version);
         const bool keep = (flags & ADX_FLAG_KEEP_MAPS) != 0;
         if (keep && maps_batch != B) { set_error("sample_a: ADX_FLAG_KEEP_MAPS without a previous call at this batch size"); return ADX_EINVAL; }
+        const bool dev_noise = !noise && !(flags & ADX_FLAG_INIT_ZERO);
+        if (dev_noise) ADX_TRY(device_noise(1, B, &noise, &n_noise));
+        char shape[160], ptrs[200];
+        snprintf(shape, sizeof shape, "s|%d|%d|%u|%d|%d", B, n_noise, flags, schedule_version, (int)dev_noise);
+        snprintf(ptrs, sizeof ptrs, "|%p|%p|%p|%p|%p|%p|%p", keep ? nullptr : (const void*)maps, (const void*)tran, (const void*)prior,
+                 dev_noise ? nullptr : (const void*)noise, (void*)out, (void*)trace_x, (void*)trace_out);
+        const bool staged = !trace_x && !trace_out && use_staging(shape, ptrs, flags);
+        const size_t maps_b = (cfg.map_cond && !keep) ? sizeof(float) * (size_t)B * nmaps * cfg.maps_dim : 0;
+        const size_t tp_b = sizeof(float) * (size_t)B * NP * Cp, out_b = sizeof(float) * (size_t)B * T * Cin;
+        const size_t noise_b = (noise && !dev_noise) ? sizeof(float) * (size_t)n_noise * B * T * Cin : 0;
+        float* g_out = out;
+        if (staged) {
+            StagePlan pl;
+            const size_t o_maps = pl.take(maps_b), o_tran = pl.take(tp_b), o_prior = pl.take(tp_b), o_noise = pl.take(noise_b), o_out = pl.take(out_b);
+            ADX_TRY(ensure_stage(pl.total));
+            auto stage_in = [&](const float*& p, size_t off, size_t bytes) -> hipError_t {
+                if (!bytes || !p) return hipSuccess;
+                hipError_t e = hipMemcpyAsync(stage_buf + off, p, bytes, hipMemcpyDeviceToDevice, s);
+                p = reinterpret_cast<const float*>(stage_buf + off);
+                return e;
+            };
+            ADX_HIP(stage_in(maps, o_maps, maps_b));
+            ADX_HIP(stage_in(tran, o_tran, tp_b));
+            ADX_HIP(stage_in(prior, o_prior, tp_b));
+            ADX_HIP(stage_in(noise, o_noise, noise_b));
+            g_out = reinterpret_cast<float*>(stage_buf + o_out);
+        }
+        if (dev_noise) ADX_TRY(push_noise_ctl(s));
         maps_batch = B;
-        return run(key, flags, s, [&](hipStream_t cs) -> int {
+        const std::string key = std::string(shape) + (staged ? "|staged" : ptrs);
+        const int rc = run(key, flags, s, [&](hipStream_t cs) -> int {
+            if (dev_noise) ADX_HIP(randn_rows(noise_ctl, noise_buf, n_noise, B, T * Cin, cs));
             if (!keep) {
                 ADX_TRY(embed_maps(B, maps, cs));
                 ADX_TRY(build_map_cache(B, cs));
             }
-            return sample_body(B, tran, prior, noise, n_noise, out, (int64_t)T * Cin, trace_x, trace_out, flags, cs);
+            return sample_body(B, tran, prior, noise, n_noise, g_out, (int64_t)T * Cin, trace_x, trace_out, flags, cs);
         });
+        if (rc == ADX_OK && staged) ADX_HIP(hipMemcpyAsync(out, g_out, out_b, hipMemcpyDeviceToDevice, s));
+        return rc;
     }
 
     int generate(int B, int S, int fs, const float* maps, const float* prior_full, const float* init_x, const float* noise,
@@ -729,10 +774,38 @@ struct EngineA final : adx_engine {
         if (fs * 4 != T * Cin || NP * Cp != fs * 4) { set_error("generate_a: frame_stack does not match the engine's token layout"); return ADX_EINVAL; }
         const int n_chunks = S / fs;
         const int chunk = fs * 4;                       // floats per batch item per chunk
-        char key[256];
-        snprintf(key, sizeof key, "g|%d|%d|%d|%p|%p|%p|%p|%d|%p|%u|%d", B, S, fs, (const void*)maps, (const void*)prior_full,
-                 (const void*)init_x, (const void*)noise, n_noise, (void*)out, flags, schedule_version);
-        return run(key, flags, s, [&](hipStream_t cs) -> int {
+        const bool dev_noise = !noise && !(flags & ADX_FLAG_INIT_ZERO);
+        if (dev_noise) ADX_TRY(device_noise(n_chunks, B, &noise, &n_noise));
+        char shape[160], ptrs[160];
+        snprintf(shape, sizeof shape, "g|%d|%d|%d|%d|%u|%d|%d", B, S, fs, n_noise, flags, schedule_version, (int)dev_noise);
+        snprintf(ptrs, sizeof ptrs, "|%p|%p|%p|%p|%p", (const void*)maps, (const void*)prior_full, (const void*)init_x,
+                 dev_noise ? nullptr : (const void*)noise, (void*)out);
+        const bool staged = use_staging(shape, ptrs, flags);
+        const size_t maps_b = cfg.map_cond ? sizeof(float) * (size_t)B * nmaps * cfg.maps_dim : 0;
+        const size_t traj_b = sizeof(float) * (size_t)B * S * 4, init_b = sizeof(float) * (size_t)chunk;
+        const size_t noise_b = (noise && !dev_noise) ? sizeof(float) * (size_t)n_chunks * n_noise * B * chunk : 0;
+        float* g_out = out;
+        if (staged) {
+            StagePlan pl;
+            const size_t o_maps = pl.take(maps_b), o_prior = pl.take(traj_b), o_init = pl.take(init_b), o_noise = pl.take(noise_b), o_out = pl.take(traj_b);
+            ADX_TRY(ensure_stage(pl.total));
+            auto stage_in = [&](const float*& p, size_t off, size_t bytes) -> hipError_t {
+                if (!bytes || !p) return hipSuccess;
+                hipError_t e = hipMemcpyAsync(stage_buf + off, p, bytes, hipMemcpyDeviceToDevice, s);
+                p = reinterpret_cast<const float*>(stage_buf + off);
+                return e;
+            };
+            ADX_HIP(stage_in(maps, o_maps, maps_b));
+            ADX_HIP(stage_in(prior_full, o_prior, traj_b));
+            ADX_HIP(stage_in(init_x, o_init, init_b));
+            ADX_HIP(stage_in(noise, o_noise, noise_b));
+            g_out = reinterpret_cast<float*>(stage_buf + o_out);
+        }
+        if (dev_noise) ADX_TRY(push_noise_ctl(s));
+        maps_batch = -1;                    // generate() embeds the maps itself; a later KEEP_MAPS sample call must not trust them
+        const std::string key = std::string(shape) + (staged ? "|staged" : ptrs);
+        const int rc = run(key, flags, s, [&](hipStream_t cs) -> int {
+            if (dev_noise) ADX_HIP(randn_rows(noise_ctl, noise_buf, n_chunks * n_noise, B, chunk, cs));
             ADX_TRY(embed_maps(B, maps, cs));
             prof_begin(5, cs);
             ADX_TRY(build_map_cache(B, cs));
@@ -740,12 +813,14 @@ struct EngineA final : adx_engine {
             for (int c = 0; c < n_chunks; ++c) {
                 ADX_HIP(copy2d(prior_full + (int64_t)c * chunk, (int64_t)S * 4, 0, PRAW, chunk, B, chunk, cs));
                 if (c == 0) ADX_HIP(copy2d(init_x, chunk, 1, TRAW, chunk, B, chunk, cs));
-                else ADX_HIP(copy2d(out + (int64_t)(c - 1) * chunk, (int64_t)S * 4, 0, TRAW, chunk, B, chunk, cs));
+                else ADX_HIP(copy2d(g_out + (int64_t)(c - 1) * chunk, (int64_t)S * 4, 0, TRAW, chunk, B, chunk, cs));
                 const float* nz = noise ? noise + (int64_t)c * n_noise * B * chunk : nullptr;
-                ADX_TRY(sample_body(B, TRAW, PRAW, nz, n_noise, out + (int64_t)c * chunk, (int64_t)S * 4, nullptr, nullptr, flags, cs));
+                ADX_TRY(sample_body(B, TRAW, PRAW, nz, n_noise, g_out + (int64_t)c * chunk, (int64_t)S * 4, nullptr, nullptr, flags, cs));
             }
             return ADX_OK;
         });
+        if (rc == ADX_OK && staged) ADX_HIP(hipMemcpyAsync(out, g_out, traj_b, hipMemcpyDeviceToDevice, s));
+        return rc;
     }
 };
 
@@ -794,7 +869,6 @@ ADX_API int adx_sample_a(adx_engine* e, int B, const float* maps, const float* t
     EngineA* a = as_a(e, "sample_a");
     if (!a) return ADX_EINVAL;
     if (!transition || !prior || !out || (a->cfg.map_cond && !maps)) { set_error("sample_a: null pointer"); return ADX_EINVAL; }
-    if (!noise && !(flags & ADX_FLAG_INIT_ZERO)) { set_error("sample_a: noise is required unless ADX_FLAG_INIT_ZERO"); return ADX_EINVAL; }
     return a->sample(B, maps, transition, prior, noise, n_noise, out, trace_x, trace_out, flags, (hipStream_t)stream);
 }
 
@@ -803,6 +877,5 @@ ADX_API int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const f
     EngineA* a = as_a(e, "generate_a");
     if (!a) return ADX_EINVAL;
     if (!prior_full || !init_x || !out || (a->cfg.map_cond && !maps)) { set_error("generate_a: null pointer"); return ADX_EINVAL; }
-    if (!noise && !(flags & ADX_FLAG_INIT_ZERO)) { set_error("generate_a: noise is required unless ADX_FLAG_INIT_ZERO"); return ADX_EINVAL; }
     return a->generate(B, S, frame_stack, maps, prior_full, init_x, noise, n_noise, out, flags, (hipStream_t)stream);
 }

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace adx {
 
 static thread_local std::string g_err;
@@ -35,6 +37,9 @@ adx_engine::~adx_engine() {
         if (kv.second.bf16lo) (void)hipFree(kv.second.bf16lo);
     }
     if (ws) (void)hipFree(ws);
+    if (stage_buf) (void)hipFree(stage_buf);
+    if (noise_buf) (void)hipFree(noise_buf);
+    if (noise_ctl) (void)hipFree(noise_ctl);
     if (steps_dev) (void)hipFree(steps_dev);
     if (steps_t_dev) (void)hipFree(steps_t_dev);
     if (temb_table) (void)hipFree(temb_table);
@@ -126,7 +131,73 @@ int adx_engine::finalize() {
     }
     ADX_HIP(hipStreamSynchronize(nullptr));
     finalized = true;
+    if (!steps.empty()) {
+        // The schedule tables and the packed weight images of the fused kernels are derived from the parameters: rebuild
+        // them for the weights just loaded (their buffers may move, so captured graphs go too).
+        ADX_HIP(hipSetDevice(device));
+        ADX_HIP(hipDeviceSynchronize());
+        drop_graphs();
+        ADX_TRY(build_time_table(nullptr));
+        ADX_HIP(hipStreamSynchronize(nullptr));
+    }
     return ADX_OK;
+}
+
+int adx_engine::ensure_stage(size_t bytes) {
+    if (bytes <= stage_bytes && stage_buf) return ADX_OK;
+    ADX_HIP(hipSetDevice(device));
+    if (stage_buf) {
+        ADX_HIP(hipDeviceSynchronize());            // a replay that reads the old buffer may still be running
+        (void)hipFree(stage_buf);
+        stage_buf = nullptr; stage_bytes = 0;
+        drop_graphs();                              // staged graphs hold the old addresses
+    }
+    hipError_t e = hipMalloc(&stage_buf, bytes);
+    if (e != hipSuccess) { stage_buf = nullptr; return fail(ADX_ENOMEM, "staging buffer: hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+    stage_bytes = bytes;
+    return ADX_OK;
+}
+
+bool adx_engine::use_staging(const std::string& shape_key, const std::string& ptr_key, unsigned flags) {
+    if ((flags & ADX_FLAG_NO_GRAPH) || profiling) return false;      // eager calls read the caller's buffers directly
+    if (io_modes.size() > 256) io_modes.clear();
+    IoMode& m = io_modes[shape_key];
+    if (m.staged) return true;
+    if (m.ptr_key.empty()) { m.ptr_key = ptr_key; return false; }
+    if (m.ptr_key == ptr_key) return false;
+    m.staged = true;                                                  // the pointers of this shape change between calls
+    return true;
+}
+
+int adx_engine::ensure_noise(size_t bytes) {
+    ADX_HIP(hipSetDevice(device));
+    if (!noise_ctl) {
+        ADX_HIP(hipMalloc(&noise_ctl, 2 * sizeof(uint64_t)));
+        ADX_HIP(hipMemset(noise_ctl, 0, 2 * sizeof(uint64_t)));
+    }
+    if (bytes <= noise_bytes && noise_buf) return ADX_OK;
+    if (noise_buf) {
+        ADX_HIP(hipDeviceSynchronize());
+        (void)hipFree(noise_buf);
+        noise_buf = nullptr; noise_bytes = 0;
+        drop_graphs();
+    }
+    hipError_t e = hipMalloc(&noise_buf, bytes);
+    if (e != hipSuccess) { noise_buf = nullptr; return fail(ADX_ENOMEM, "noise buffer: hipMalloc of " + std::to_string(bytes) + " bytes failed"); }
+    noise_bytes = bytes;
+    return ADX_OK;
+}
+
+int adx_engine::push_noise_ctl(hipStream_t s) {
+    ADX_HIP(set_noise_ctl(noise_ctl, noise_seed, noise_row0, s));
+    return ADX_OK;
+}
+
+int adx_engine::n_schedule_draws() const {
+    int n = 0;
+    for (const adx_step_coef& k : steps)
+        if (k.c3 != 0.f && k.z_index >= 0.f) n = std::max(n, (int)k.z_index + 1);
+    return n;
 }
 
 int adx_engine::reserve(int batch) {
@@ -144,6 +215,7 @@ int adx_engine::reserve(int batch) {
     }
     ws_bytes = bytes;
     max_batch = batch;
+    on_workspace_realloc();
     return carve_workspace(batch, false, &bytes);
 }
 
@@ -360,6 +432,38 @@ ADX_API int adx_engine_profile(adx_engine* e, int enable) {
 ADX_API int adx_engine_profile_read(adx_engine* e, int stage, double* total_ms, int* count) {
     if (!e) return fail(ADX_EINVAL, "profile_read: null engine");
     return e->profile_read(stage, total_ms, count);
+}
+
+ADX_API int64_t adx_engine_capture_count(const adx_engine* e) { return e ? e->n_captures : 0; }
+
+ADX_API int adx_engine_set_noise_seed(adx_engine* e, uint64_t seed, int64_t row0) {
+    if (!e) return fail(ADX_EINVAL, "set_noise_seed: null engine");
+    if (row0 < 0) return fail(ADX_EINVAL, "set_noise_seed: negative row offset");
+    e->noise_seed = seed;
+    e->noise_row0 = (uint64_t)row0;
+    return ADX_OK;
+}
+
+ADX_API int adx_op_randn(float* out, int n_lead, int B, int row_len, uint64_t seed, int64_t row0, uint64_t* ctl_scratch, void* stream) {
+    if (!out || !ctl_scratch) return fail(ADX_EINVAL, "randn: null pointer");
+    if (n_lead <= 0 || B <= 0 || row_len <= 0 || row0 < 0) return fail(ADX_EINVAL, "randn: bad shape");
+    hipError_t he = set_noise_ctl(ctl_scratch, seed, (uint64_t)row0, (hipStream_t)stream);
+    if (he == hipSuccess) he = randn_rows(ctl_scratch, out, n_lead, B, row_len, (hipStream_t)stream);
+    return done(he, "randn");
+}
+
+ADX_API int adx_op_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp,
+                            float* xt, float* v, int n_rows, int row_len, void* stream) {
+    if (!x0 || !noise || !t || !sqrt_acp || !sqrt_1m_acp || !xt) return fail(ADX_EINVAL, "q_sample: null pointer");
+    if (n_rows <= 0 || row_len <= 0) return fail(ADX_EINVAL, "q_sample: empty shape");
+    return done(q_sample(x0, noise, t, sqrt_acp, sqrt_1m_acp, xt, v, n_rows, row_len, (hipStream_t)stream), "q_sample");
+}
+
+ADX_API int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows,
+                                float* loss_mean, int n_rows, int row_len, void* stream) {
+    if (!out || !target || !t || !weight || !loss_rows) return fail(ADX_EINVAL, "weighted_mse: null pointer");
+    if (n_rows <= 0 || row_len <= 0) return fail(ADX_EINVAL, "weighted_mse: empty shape");
+    return done(weighted_mse(out, target, t, weight, loss_rows, loss_mean, n_rows, row_len, (hipStream_t)stream), "weighted_mse");
 }
 
 ADX_API int adx_engine_reserve(adx_engine* e, int max_batch) {

@@ -288,14 +288,39 @@ struct EngineDiT final : adx_engine {
         if (steps.empty()) { set_error("sample_dit: no schedule set"); return ADX_ESTATE; }
         if (cfg.in_dim != cfg.out_dim) { set_error("sample_dit: in_dim must equal out_dim"); return ADX_EINVAL; }
         const int64_t n = (int64_t)B * S * C;
+        const bool dev_noise = !noise && !(flags & ADX_FLAG_INIT_ZERO);
+        if (dev_noise) {
+            n_noise = 1 + n_schedule_draws();
+            ADX_TRY(ensure_noise(sizeof(float) * (size_t)n_noise * n));
+            noise = noise_buf;
+        }
         for (const adx_step_coef& k : steps)
             if (k.c3 != 0.f && k.z_index >= 0 && (!noise || 1 + (int)k.z_index >= n_noise)) {
                 set_error("sample_dit: schedule draws more noise tensors than were supplied"); return ADX_EINVAL;
             }
-        char key[256];
-        snprintf(key, sizeof key, "d|%d|%p|%p|%d|%p|%u|%d", B, (const void*)state, (const void*)noise, n_noise, (void*)out, flags,
-                 schedule_version);
-        return run(key, flags, s, [&](hipStream_t cs) -> int {
+        char shape[160], ptrs[120];
+        snprintf(shape, sizeof shape, "d|%d|%d|%u|%d|%d", B, n_noise, flags, schedule_version, (int)dev_noise);
+        snprintf(ptrs, sizeof ptrs, "|%p|%p|%p", (const void*)state, dev_noise ? nullptr : (const void*)noise, (void*)out);
+        const bool staged = use_staging(shape, ptrs, flags);
+        const size_t state_b = sizeof(float) * (size_t)B * S * d, out_b = sizeof(float) * (size_t)n;
+        const size_t noise_b = (noise && !dev_noise) ? sizeof(float) * (size_t)n_noise * n : 0;
+        float* g_out = out;
+        if (staged) {
+            auto slot = [](size_t b) { return (b + 255) / 256 * 256; };
+            const size_t o_state = 0, o_noise = slot(state_b), o_out = o_noise + slot(noise_b);
+            ADX_TRY(ensure_stage(o_out + slot(out_b)));
+            ADX_HIP(hipMemcpyAsync(stage_buf + o_state, state, state_b, hipMemcpyDeviceToDevice, s));
+            state = reinterpret_cast<const float*>(stage_buf + o_state);
+            if (noise_b) {
+                ADX_HIP(hipMemcpyAsync(stage_buf + o_noise, noise, noise_b, hipMemcpyDeviceToDevice, s));
+                noise = reinterpret_cast<const float*>(stage_buf + o_noise);
+            }
+            g_out = reinterpret_cast<float*>(stage_buf + o_out);
+        }
+        if (dev_noise) ADX_TRY(push_noise_ctl(s));
+        const std::string key = std::string(shape) + (staged ? "|staged" : ptrs);
+        const int rc = run(key, flags, s, [&](hipStream_t cs) -> int {
+            if (dev_noise) ADX_HIP(randn_rows(noise_ctl, noise_buf, n_noise, B, S * C, cs));
             ADX_TRY(encode_state(B, state, cs));
             float* xc = XS0; float* xn = XS1;
             if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, cs));
@@ -307,10 +332,12 @@ struct EngineDiT final : adx_engine {
                 ADX_HIP(sched_step(xc, MOUT, z, xn, nullptr, n, steps_dev + k, cs));
                 std::swap(xc, xn);
             }
-            if (flags & ADX_FLAG_NORMALIZE) ADX_HIP(denormalize_traj(xc, nullptr, out, n / C, C, cs));
-            else ADX_HIP(copy2d(xc, n, 0, out, n, 1, (int)n, cs));
+            if (flags & ADX_FLAG_NORMALIZE) ADX_HIP(denormalize_traj(xc, nullptr, g_out, n / C, C, cs));
+            else ADX_HIP(copy2d(xc, n, 0, g_out, n, 1, (int)n, cs));
             return ADX_OK;
         });
+        if (rc == ADX_OK && staged) ADX_HIP(hipMemcpyAsync(out, g_out, out_b, hipMemcpyDeviceToDevice, s));
+        return rc;
     }
 };
 
@@ -346,6 +373,5 @@ ADX_API int adx_sample_dit(adx_engine* e, int B, const float* state, const float
     EngineDiT* a = as_dit(e, "sample_dit");
     if (!a) return ADX_EINVAL;
     if (!state || !out) { set_error("sample_dit: null pointer"); return ADX_EINVAL; }
-    if (!noise && !(flags & ADX_FLAG_INIT_ZERO)) { set_error("sample_dit: noise is required unless ADX_FLAG_INIT_ZERO"); return ADX_EINVAL; }
     return a->sample(B, state, noise, n_noise, out, flags, (hipStream_t)stream);
 }

@@ -7,7 +7,7 @@ the HF Trainer performs around ``prediction_step`` (transformer4planning/trainer
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -20,23 +20,59 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: torch.Tensor, total: int) -> torch.Tensor:
-    """Concatenate every rank's rows (dim 0) in rank order on every rank.
+class RowGatherer:
+    """All-gather of every rank's rows (dim 0) in rank order, with every buffer allocated once.
 
-    Shards may differ by one row; they are padded to the largest shard for the collective (the same trick the
-    reference's evaluation loop uses to keep ragged last batches from hanging a gather) and trimmed after.
+    The collective is enqueued behind the work already on the current stream of ``local`` (the sampling stream) and
+    writes straight into a preallocated ``(world * max_rows, ...)`` tensor; nothing is allocated or concatenated per call.
+    Shards may differ by one row (``total`` not a multiple of the world size): the short shards are padded to the largest
+    for the collective -- the trick the reference's evaluation loop uses to keep ragged last batches from hanging a
+    gather (trainer.py:665-692) -- and ``gather`` then compacts the rows in place, again without allocating.
     """
+
+    def __init__(self, total: int, row_shape: Tuple[int, ...], device, dtype=torch.float32):
+        self.total = int(total)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.spans = [shard_range(self.total, r, self.world) for r in range(self.world)]
+        self.max_rows = max(hi - lo for lo, hi in self.spans)
+        self.ragged = any(hi - lo != self.max_rows for lo, hi in self.spans)
+        self.out = torch.empty(self.world * self.max_rows, *row_shape, device=device, dtype=dtype)
+        lo, hi = self.spans[self.rank]
+        self.rows = hi - lo
+        self.pad: Optional[torch.Tensor] = None
+        if self.rows < self.max_rows:
+            self.pad = torch.zeros(self.max_rows, *row_shape, device=device, dtype=dtype)
+        self.tmp = torch.empty(self.max_rows, *row_shape, device=device, dtype=dtype) if self.ragged else None
+
+    def gather(self, local: torch.Tensor) -> torch.Tensor:
+        """-> (total, ...) rows of all ranks, a view of the preallocated buffer (valid until the next call)."""
+        if self.world == 1:
+            return local
+        if local.shape[0] != self.rows:
+            raise ValueError(f"rank {self.rank} owns {self.rows} rows, got {local.shape[0]}")
+        src = local.contiguous()
+        if self.pad is not None:
+            self.pad[: self.rows].copy_(src)
+            src = self.pad
+        if src.is_cuda:
+            dist.all_gather_into_tensor(self.out, src)
+        else:                                   # gloo has no all_gather_into_tensor: gather into views of the same buffer
+            dist.all_gather(list(self.out.view(self.world, self.max_rows, *self.out.shape[1:]).unbind(0)), src)
+        if not self.ragged:
+            return self.out
+        # compact in place, front to back (a shard's destination never lies behind its source; the two may overlap, hence
+        # the bounce through the preallocated shard-sized buffer)
+        for r, (lo, hi) in enumerate(self.spans):
+            s0 = r * self.max_rows
+            if s0 != lo:
+                self.tmp[: hi - lo].copy_(self.out[s0:s0 + (hi - lo)])
+                self.out[lo:hi].copy_(self.tmp[: hi - lo])
+        return self.out[: self.total]
+
+
+def all_gather_rows(local: torch.Tensor, total: int) -> torch.Tensor:
+    """One-shot form of ``RowGatherer`` (allocates its buffers; a loop should keep a ``RowGatherer``)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    world = dist.get_world_size()
-    sizes = [shard_range(total, r, world) for r in range(world)]
-    max_rows = max(hi - lo for lo, hi in sizes)
-    padded = local
-    if local.shape[0] < max_rows:
-        pad = torch.zeros(max_rows - local.shape[0], *local.shape[1:], dtype=local.dtype, device=local.device)
-        padded = torch.cat([local, pad], dim=0)
-    out = torch.empty(world * max_rows, *local.shape[1:], dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous()) if local.is_cuda else \
-        dist.all_gather(list(out.view(world, max_rows, *local.shape[1:]).unbind(0)), padded.contiguous())
-    parts = [out[r * max_rows: r * max_rows + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
-    return torch.cat(parts, dim=0)
+    return RowGatherer(total, tuple(local.shape[1:]), local.device, local.dtype).gather(local)

@@ -206,17 +206,35 @@ class DiffusionWrapper(nn.Module):
 
     def forward(self, hidden_state, batch_size=0, label=None, info_dict=None, get_inter=False, **kwargs):
         if self.training:
-            raise NotImplementedError("the training loss is outside the accelerated sampling path; call .eval()")
+            return self.train_forward(hidden_state, label, info_dict=info_dict, **kwargs)
         assert batch_size > 0
         return self.sample_forward(hidden_state, batch_size, info_dict=info_dict, get_inter=get_inter, **kwargs)
 
     @torch.no_grad()
+    def train_forward(self, hidden_state, trajectory_label, info_dict=None, t: Optional[torch.Tensor] = None,
+                      noise: Optional[torch.Tensor] = None):
+        """Forward-only value of the training loss (diffusion_decoder.py:346-365): normalise the label, q_sample at one random
+        timestep per row, one denoiser call; returns the element-wise squared error (B, S, C) as the reference does."""
+        from . import ops
+        x0 = ops.normalize(_lib.f32c(trajectory_label))
+        B = x0.shape[0]
+        if t is None:
+            t = torch.randint(0, self.n_timesteps, (B,), device=x0.device)
+        t = t.to(device=x0.device, dtype=torch.int64).contiguous()
+        noise = torch.randn_like(x0) if noise is None else _lib.f32c(noise)
+        x_noisy, _ = ops.q_sample(x0, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        x_recon = self.model(x_noisy, t, hidden_state, info_dict=info_dict)
+        return (x_recon - noise) ** 2
+
+    @torch.no_grad()
     def sample_forward(self, state, batch_size, info_dict=None, get_inter=False, mc_num=1, determin=True,
-                       noise: Optional[torch.Tensor] = None, return_scores: bool = False, **kwargs):
+                       noise: Optional[torch.Tensor] = None, return_scores: bool = False, seed: Optional[int] = None, row0: int = 0,
+                       **kwargs):
         """Returns the de-normalised trajectories: (B, S, C) for mc_num == 1, (B, mc_num, S, C) otherwise.
 
-        With ``return_scores`` also returns ``total_cls`` = -mean(x_N^2, dim=1) - sum_steps mean(z^2, dim=1), the
-        sample score the reference accumulates; it depends on the noise only.
+        ``noise`` (1 + draws, B * mc_num, S, C): None draws it on the device (``seed``, ``row0``: generator seed and global index
+        of row 0 of the B * mc_num sample rows).  With ``return_scores`` also returns ``total_cls`` = -mean(x_N^2, dim=1) -
+        sum_steps mean(z^2, dim=1), the sample score the reference accumulates; it depends on the noise only.
         """
         if get_inter:
             raise NotImplementedError("get_inter is not supported")
@@ -235,7 +253,14 @@ class DiffusionWrapper(nn.Module):
             flags |= _lib.FLAG_INIT_ZERO
             noise = None
         elif noise is None:
-            noise = torch.randn(1 + schedules.n_noise_draws(rows), B, seq_len, self.action_dim, device=state.device)
+            if return_scores:       # the scores are a function of the noise: materialise it (same generator, same values)
+                from . import ops
+                if seed is None:
+                    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+                noise = ops.randn(1 + schedules.n_noise_draws(rows), B, seq_len * self.action_dim, seed, row0,
+                                  device=state.device).reshape(-1, B, seq_len, self.action_dim)
+            else:
+                eng.seed_from_torch(seed, row0)
         out = eng.sample_dit(_lib.f32c(state), _lib.f32c(noise) if noise is not None else None, flags)
         if mc_num > 1:
             out = out.reshape(batch_size, mc_num, *out.shape[1:])
@@ -266,19 +291,28 @@ class DiffusionDecoder(nn.Module):
         self.model = DiffusionWrapper(net, beta_schedule=config.beta_schedule, n_timesteps=config.diffusion_timesteps,
                                       predict_range=self.predict_range)
 
-    def forward(self, label, hidden_output, info_dict=None, device=None):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
+    @torch.no_grad()
+    def forward(self, label, hidden_output, info_dict=None, device=None, t: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None):
+        """-> (loss, logits): summed squared error of the noise estimate times ``trajectory_loss_rescale`` and all-zero logits
+        (diffusion_decoder.py:502-532), forward only."""
+        if not self.config.predict_yaw:
+            label = label[..., :2].clone()
+        loss = self.model.train_forward(hidden_output, label, info_dict=info_dict, t=t, noise=noise).sum()
+        return loss * float(getattr(self.config, "trajectory_loss_rescale", 1.0)), torch.zeros_like(label)
 
     @torch.no_grad()
-    def generate(self, hidden_output, info_dict=None, noise: Optional[torch.Tensor] = None):
+    def generate(self, hidden_output, info_dict=None, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, row0: int = 0):
         pred_traj_num = hidden_output.shape[0]
         assert self.config.predict_range > 0 and pred_traj_num > 0
         if self.k == 1:
             return self.model(hidden_output, info_dict=info_dict, batch_size=pred_traj_num, determin=True)
-        traj, scores = self.model(hidden_output, info_dict=info_dict, batch_size=pred_traj_num, determin=False,
-                                  mc_num=self.config.mc_num, noise=noise, return_scores=True)
+        # the reference also receives the samples' scores here, but its mode selection multiplies them by zero
+        # (utils/modify_traj_utils.py:183-184), so they are not computed
+        traj = self.model(hidden_output, info_dict=info_dict, batch_size=pred_traj_num, determin=False,
+                          mc_num=self.config.mc_num, noise=noise, seed=seed, row0=row0)
         if self.config.mc_num > self.k:
-            traj, scores = select_k_from_mc(traj, scores, self.k)
+            traj, _ = select_k_from_mc(traj, None, self.k)
         return traj
 
 

@@ -44,8 +44,7 @@ class Engine:
                 t = t.cuda()
             shape = (C.c_int64 * t.dim())(*t.shape)
             check(self.lib.adx_engine_set_tensor(self.h, name.encode(), ptr(t), shape, t.dim()), f"set_tensor({name})")
-        check(self.lib.adx_engine_finalize(self.h), "adx_engine_finalize")
-        self._rows = None  # set_tensor invalidates nothing on the schedule, but keep the cache honest
+        check(self.lib.adx_engine_finalize(self.h), "adx_engine_finalize")   # rebuilds the weight-derived tables of a set schedule
 
     def sync_from(self, module: torch.nn.Module, prefix: str = ""):
         """(Re)load the parameters of ``module`` if any changed since the last call."""
@@ -60,6 +59,20 @@ class Engine:
 
     def workspace_bytes(self) -> int:
         return int(self.lib.adx_engine_workspace_bytes(self.h))
+
+    def capture_count(self) -> int:
+        """hipGraph captures made by this engine so far."""
+        return int(self.lib.adx_engine_capture_count(self.h))
+
+    def set_noise_seed(self, seed: int, row0: int = 0):
+        """Seed and global index of batch row 0 for sampling calls that pass ``noise=None`` (noise drawn on the device)."""
+        check(self.lib.adx_engine_set_noise_seed(self.h, int(seed) & 0xFFFFFFFFFFFFFFFF, int(row0)), "adx_engine_set_noise_seed")
+
+    def seed_from_torch(self, seed: Optional[int] = None, row0: int = 0):
+        """``seed`` None: a fresh 63-bit seed from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self.set_noise_seed(seed, row0)
 
     # ------------------------------------------------------------------ schedule
     def set_schedule(self, rows: Sequence[Sequence[float]]):

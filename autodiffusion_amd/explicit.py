@@ -55,40 +55,47 @@ class TrajDiffusion(nn.Module):
         lead = (n,) if n_chunks is None else (n_chunks, n)
         return torch.randn(*lead, batch, 1, self.cfg.trajectory_dim * self.cfg.frame_stack, device=device)
 
-    def _staging(self, B: int, n_noise: int, device):
-        """Persistent per-(batch, device) buffers for the per-chunk tensors: the engine keys its captured hipGraph on the
-        pointers it is given, and the chunk loop would otherwise hand it fresh tensors (a new capture) for every chunk."""
-        key = (B, n_noise, str(device))
-        if getattr(self, "_stage_key", None) != key:
-            W = self.cfg.trajectory_dim * self.cfg.frame_stack
-            f = dict(device=device, dtype=torch.float32)
-            self._stage = (torch.empty(B, 1, W, **f), torch.empty(B, 1, W, **f), torch.empty(n_noise, B, 1, W, **f), torch.empty(B, 1, W, **f))
-            self._stage_key = key
-        return self._stage
-
     @torch.no_grad()
     def generate(self, label, transition_info, trajectory_prior, maps_info, noise: Optional[torch.Tensor] = None,
-                 same_maps: bool = False):
+                 same_maps: bool = False, seed: Optional[int] = None, row0: int = 0):
         """label (B, fs*4) [shape only], transition_info (B, fs*4) or (B, 1, fs*4), trajectory_prior (B, fs*4),
-        maps_info (B, 788, maps_dim) -> (B, fs*4).  ``noise``: (1 + draws, B, 1, fs*4), default fresh N(0, 1).
-        ``same_maps``: maps_info is the tensor of the previous call (the next chunk of the same trajectories), so its
-        embedding and attention caches are kept."""
+        maps_info (B, 788, maps_dim) -> (B, fs*4).  ``noise``: (1 + draws, B, 1, fs*4); None draws it on the device
+        (``seed``, ``row0``).  ``same_maps``: maps_info is the tensor of the previous call (the next chunk of the same
+        trajectories), so its embedding and attention caches are kept.  (Per-chunk tensors are fresh on every call; the
+        engine serves such callers from its own staging buffers, one captured graph for all of them.)"""
         B = label.shape[0]
-        if transition_info.dim() == 2:
-            transition_info = transition_info.unsqueeze(1)
-        prior = trajectory_prior.unsqueeze(1) if trajectory_prior.dim() == 2 else trajectory_prior
+        W = self.cfg.trajectory_dim * self.cfg.frame_stack
         eng = self.diffusion.engine()
         eng.set_schedule(self.schedule_rows())
         if noise is None:
-            noise = self.make_noise(B, prior.device)
+            eng.seed_from_torch(seed, row0)
         maps = _lib.f32c(maps_info) if self.diffusion.map_cond else None
-        tb, pb, nb, ob = self._staging(B, noise.shape[0], prior.device)
-        tb.copy_(transition_info.reshape(tb.shape)); pb.copy_(prior.reshape(pb.shape)); nb.copy_(noise.reshape(nb.shape))
-        eng.sample_a(maps, tb, pb, nb, _lib.FLAG_KEEP_MAPS if same_maps else 0, out=ob)
-        return ob.squeeze(1).clone()
+        out = eng.sample_a(maps, _lib.f32c(transition_info).reshape(B, 1, W), _lib.f32c(trajectory_prior).reshape(B, 1, W),
+                           _lib.f32c(noise).reshape(-1, B, 1, W) if noise is not None else None,
+                           _lib.FLAG_KEEP_MAPS if same_maps else 0)
+        return out.squeeze(1)
 
-    def forward(self, label, transition_info, trajectory_prior, maps_info):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
+    @torch.no_grad()
+    def forward(self, label, transition_info, trajectory_prior, maps_info, t: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None):
+        """-> (loss (B, fs*4) element-wise squared error of the noise estimate, pred (B, fs*4)): traj_diffusion.py:83-124,
+        forward only.  The timestep is uniform in [1, num_train_timesteps) as there; ``add_noise`` is the public
+        ``sqrt(acp[t]) x + sqrt(1 - acp[t]) noise`` (third-party scheduler: parity unpinned)."""
+        from . import ops
+        B = label.shape[0]
+        W = self.cfg.trajectory_dim * self.cfg.frame_stack
+        x0 = _lib.f32c(label).reshape(B, 1, W)
+        sc = self.cfg.scheduler
+        if t is None:
+            t = torch.randint(1, sc.num_train_timesteps, (B,), device=x0.device)
+        t = t.to(device=x0.device, dtype=torch.int64).contiguous()
+        noise = torch.randn_like(x0) if noise is None else _lib.f32c(noise).reshape(B, 1, W)
+        acp = torch.cumprod(1.0 - self.betas.to(torch.float32), dim=0)
+        x, _ = ops.q_sample(x0, noise, t, acp.sqrt(), (1.0 - acp).sqrt())
+        cond = dict(maps_info=maps_info, transition_info=_lib.f32c(transition_info).reshape(B, 1, W),
+                    trajectory_prior=_lib.f32c(trajectory_prior).reshape(B, 1, W))
+        pred = self.diffusion(x, t, cond).reshape(B, W)
+        return (pred - noise.reshape(B, W)) ** 2, pred
 
 
 class ExplicitDiT(nn.Module):
@@ -116,35 +123,69 @@ class ExplicitDiT(nn.Module):
     def _unnormalize_x(self, xs):
         return xs * self.data_std.to(xs.device) + self.data_mean.to(xs.device)
 
-    @torch.no_grad()
-    def generate(self, noise: Optional[torch.Tensor] = None, **kwargs):
-        """-> {"traj_logits": (B, 80, 4) float32}.  ``noise``: (n_chunks, 1 + draws, B, 1, fs*4)."""
+    def _normalize_x(self, xs):
+        return (xs - self.data_mean.to(xs.device)) / self.data_std.to(xs.device)
+
+    def _phase1(self, kwargs):
         if "trajectory_prior" in kwargs and "maps_info" in kwargs:
-            trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
-        else:
-            if self.str_model[0] is None:
-                raise ValueError("generate() needs either trajectory_prior/maps_info or a str_model for phase 1")
-            str_result = self.str_model[0].generate(**kwargs)
-            trajectory_prior, maps_info = str_result["traj_logits"], str_result["maps_info"]
+            return kwargs["trajectory_prior"], kwargs["maps_info"]
+        if self.str_model[0] is None:
+            raise ValueError("needs either trajectory_prior/maps_info or a str_model for phase 1")
+        str_result = self.str_model[0].generate(**kwargs)
+        return str_result["traj_logits"], str_result["maps_info"]
+
+    @torch.no_grad()
+    def generate(self, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, row0: int = 0, **kwargs):
+        """-> {"traj_logits": (B, 80, 4) float32}.  ``noise``: (n_chunks, 1 + draws, B, 1, fs*4); None draws it on the device."""
+        trajectory_prior, maps_info = self._phase1(kwargs)
         B, S, C = trajectory_prior.shape
         if S % self.frame_stack != 0:
             raise ValueError("Number of frames must be divisible by frame stack size")
         n_chunks = S // self.frame_stack
         width = self.frame_stack * C
         prior = _lib.f32c(trajectory_prior).reshape(B, n_chunks, width)
-        if noise is None:
-            noise = self.diffusion.make_noise(B, prior.device, n_chunks)
+        if noise is None and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         transition = self.init_x[None].expand(B, width).contiguous()
         label = torch.empty(B, width, device=prior.device)          # shape only
         preds = []
         for c in range(n_chunks):
-            transition = self.diffusion.generate(label, transition, prior[:, c].contiguous(), maps_info, noise=noise[c], same_maps=c > 0)
+            # device noise: every chunk takes its own stream of the generator (seed + chunk index)
+            transition = self.diffusion.generate(label, transition, prior[:, c].contiguous(), maps_info,
+                                                 noise=None if noise is None else noise[c], same_maps=c > 0,
+                                                 seed=None if noise is not None else seed + c, row0=row0)
             preds.append(transition)
         out = torch.stack(preds, dim=1).reshape(B, S, C)
         return {"traj_logits": self._unnormalize_x(out).to(torch.float32)}
 
-    def forward(self, return_dict=None, **kwargs):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path; use generate()")
+    @torch.no_grad()
+    def forward(self, return_dict=None, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
+        """Evaluation-time value of the training objective (ExplicitDiT.py:80-137), forward only: per chunk the squared error
+        of the noise estimate for the (data_mean/std-normalised) label chunk, the previous chunk's model output as transition.
+        ``t`` (n_chunks, B), ``noise`` (n_chunks, B, fs*4) fix the draws."""
+        from .refiner import LTMOutput
+        trajectory_prior, maps_info = self._phase1(kwargs)
+        trajectory_label = kwargs.get("trajectory_label", None)
+        if trajectory_label is None:
+            raise ValueError("forward() needs trajectory_label")
+        B, S, C = trajectory_prior.shape
+        if S % self.frame_stack != 0:
+            raise ValueError("Number of frames must be divisible by frame stack size")
+        n_chunks = S // self.frame_stack
+        width = self.frame_stack * C
+        prior = _lib.f32c(trajectory_prior).reshape(B, n_chunks, width)
+        label = self._normalize_x(_lib.f32c(trajectory_label.to(prior.device))).reshape(B, n_chunks, width)
+        transition = self.init_x[None].expand(B, width).contiguous()
+        losses, preds = [], []
+        for c in range(n_chunks):
+            l, transition = self.diffusion(label[:, c].contiguous(), transition, prior[:, c].contiguous(), maps_info,
+                                           t=None if t is None else t[c], noise=None if noise is None else noise[c])
+            losses.append(l)
+            preds.append(transition)
+        final_predict = self._unnormalize_x(torch.stack(preds, dim=1).reshape(B, S, C))
+        loss = torch.stack(losses)
+        return LTMOutput(loss=loss.mean(), loss_items=loss, logits=final_predict, pred_dict={"traj_logits": final_predict},
+                         trajectory_label=trajectory_label)
 
 
 def explicit_config(frame_stack: int = 10, num_train_timesteps: int = 100, num_inference_steps: int = 10,

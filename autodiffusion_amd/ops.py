@@ -130,3 +130,43 @@ def select_modes(traj: torch.Tensor, k: int, em_iter: int = 25):
     weights = torch.empty(B, k, device=traj.device, dtype=torch.float32)
     check(lib.adx_op_select_modes(ptr(traj), B, M, L, D, int(k), int(em_iter), ptr(modes), ptr(weights), current_stream()), "select_modes")
     return modes, weights
+
+
+def q_sample(x0: torch.Tensor, noise: torch.Tensor, t: torch.Tensor, sqrt_acp: torch.Tensor, sqrt_1m_acp: torch.Tensor,
+             want_v: bool = False):
+    """x_t = sqrt_acp[t] x0 + sqrt_1m_acp[t] noise with a timestep per batch row (dim 0); also v = sqrt_acp[t] noise -
+    sqrt_1m_acp[t] x0 when ``want_v``.  Returns (x_t, v or None)."""
+    lib = _lib.load()
+    x0, noise = f32c(x0), f32c(noise)
+    t = t.to(device=x0.device, dtype=torch.int64).contiguous()
+    sa, s1 = f32c(sqrt_acp).to(x0.device), f32c(sqrt_1m_acp).to(x0.device)
+    n_rows = x0.shape[0]
+    row_len = x0.numel() // n_rows
+    xt = torch.empty_like(x0)
+    v = torch.empty_like(x0) if want_v else None
+    check(lib.adx_op_q_sample(ptr(x0), ptr(noise), ptr(t), ptr(sa), ptr(s1), ptr(xt), ptr(v), n_rows, row_len, current_stream()), "q_sample")
+    return xt, v
+
+
+def weighted_mse(out: torch.Tensor, target: torch.Tensor, t: torch.Tensor, weight: torch.Tensor):
+    """(loss_rows (B,), loss_mean ()): loss_rows[b] = weight[t[b]] * mean((out[b] - target[b])**2)."""
+    lib = _lib.load()
+    out, target = f32c(out), f32c(target)
+    t = t.to(device=out.device, dtype=torch.int64).contiguous()
+    w = f32c(weight).to(out.device)
+    n_rows = out.shape[0]
+    row_len = out.numel() // n_rows
+    rows = torch.empty(n_rows, device=out.device, dtype=torch.float32)
+    mean = torch.empty(1, device=out.device, dtype=torch.float32)
+    check(lib.adx_op_weighted_mse(ptr(out), ptr(target), ptr(t), ptr(w), ptr(rows), ptr(mean), n_rows, row_len, current_stream()), "weighted_mse")
+    return rows, mean.reshape(())
+
+
+def randn(n_lead: int, batch: int, row_len: int, seed: int, row0: int = 0, device="cuda") -> torch.Tensor:
+    """(n_lead, batch, row_len) N(0,1) values from the library's counter-based generator (Philox4x32-10 + Box-Muller): the value of
+    element e of batch row b under leading index l depends only on (seed, row0 + b, l, e // 4)."""
+    lib = _lib.load()
+    out = torch.empty(n_lead, batch, row_len, device=device, dtype=torch.float32)
+    ctl = torch.empty(2, device=out.device, dtype=torch.int64)
+    check(lib.adx_op_randn(ptr(out), n_lead, batch, row_len, int(seed) & 0xFFFFFFFFFFFFFFFF, int(row0), ptr(ctl), current_stream()), "randn")
+    return out

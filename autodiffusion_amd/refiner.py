@@ -9,7 +9,9 @@ Interfaces mirrored (paths relative to the reference tree):
 
 Parameter and buffer names are the reference's, so a reference ``state_dict`` loads
 with ``load_state_dict``.  The modules only *hold* parameters; every forward runs in
-the HIP engine.  Sampling (eval mode) is implemented; the training loss is not.
+the HIP engine.  Sampling (eval mode) and the forward-only evaluation of the training
+loss (what the HF-Trainer evaluation entry computes before it samples,
+transformer4planning/trainer.py:643) are implemented; gradients are not.
 
 Deviations, all deliberate:
 * ``Transformer.forward`` returns ``(B, T, C)`` always (the reference's trailing
@@ -17,12 +19,18 @@ Deviations, all deliberate:
 * caller tensors are never modified (the reference normalises ``prior[...]`` in place
   inside the condition dict, TrajRefiner.py:322-323).
 * every sampling entry point takes an optional ``noise`` tensor so results are
-  reproducible and shard-invariant; without it, noise is drawn with ``torch.randn``.
+  reproducible and shard-invariant; without it, noise is drawn on the device inside
+  the captured graph (counter-based generator keyed by ``seed`` and the global batch
+  row ``row0 + b``; ``seed=None`` takes a fresh seed from torch's CPU generator).
+* the loss is evaluated without dropout (the reference leaves its refiner in train
+  mode inside ``forward``, DiffusionAugmentation.py:109, so its evaluation loss is a
+  dropout sample; this is the dropout-free value) and takes optional ``t`` / ``noise``.
 """
 from __future__ import annotations
 
 import math
 from types import SimpleNamespace
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -30,6 +38,19 @@ import torch.nn as nn
 
 from . import _lib, schedules
 from .engine import Engine
+
+
+class LTMOutput(OrderedDict):
+    """The reference's output record (DiffusionAugmentation.py:19-25): fields readable as attributes and as mapping items;
+    fields that are None are left out of the mapping, as transformers' ModelOutput does."""
+
+    def __init__(self, loss=None, logits=None, trajectory_label=None, loss_items=None, pred_dict=None):
+        super().__init__()
+        for k, v in (("loss", loss), ("logits", logits), ("trajectory_label", trajectory_label), ("loss_items", loss_items),
+                     ("pred_dict", pred_dict)):
+            object.__setattr__(self, k, v)
+            if v is not None:
+                self[k] = v
 
 
 # ------------------------------------------------------------------ parameter holders
@@ -219,28 +240,51 @@ class DiffusionWrapper(nn.Module):
         return (_lib.FLAG_NORMALIZE if self.auto_normalize_data else 0) | (_lib.FLAG_RESIDUAL if self.residual else 0)
 
     def make_noise(self, shape, device, n_chunks: Optional[int] = None):
+        """Host-side noise in the layout the engine reads (for callers that want the tensor; the default path draws on the device)."""
         n = 1 + schedules.n_noise_draws(self.schedule_rows())
         lead = (n,) if n_chunks is None else (n_chunks, n)
         return torch.randn(*lead, *shape, device=device, dtype=torch.float32)
 
     @torch.no_grad()
     def sample(self, prior: Dict[str, torch.Tensor], trajectory_label: torch.Tensor, return_all_timesteps: bool = False,
-               noise: Optional[torch.Tensor] = None, trace: bool = False):
+               noise: Optional[torch.Tensor] = None, trace: bool = False, seed: Optional[int] = None, row0: int = 0):
         if return_all_timesteps:
             raise NotImplementedError("return_all_timesteps is not supported; pass trace=True for per-step tensors")
         eng = self.model.engine()
         eng.set_schedule(self.schedule_rows())
-        shape = tuple(trajectory_label.shape)
-        dev = prior["trajectory_prior"].device
         if noise is None:
-            noise = self.make_noise(shape, dev)
+            eng.seed_from_torch(seed, row0)
         maps = _lib.f32c(prior["maps_info"]) if self.model.map_cond else None
         return eng.sample_a(maps, _lib.f32c(prior["transition_info"]), _lib.f32c(prior["trajectory_prior"]),
-                            _lib.f32c(noise), self.flags(), trace=trace)
+                            _lib.f32c(noise) if noise is not None else None, self.flags(), trace=trace)
+
+    @torch.no_grad()
+    def p_losses(self, prior: Dict[str, torch.Tensor], x_start: torch.Tensor, t: Optional[torch.Tensor] = None,
+                 noise: Optional[torch.Tensor] = None, return_rows: bool = False):
+        """Forward-only value of the training loss (TrajRefiner.py:417-452): normalise, q_sample at a random timestep per row,
+        one denoiser call, min-SNR weighted mean squared error.  ``t`` (B,) int64 and ``noise`` like ``x_start`` may be given."""
+        from . import ops
+        x0 = _lib.f32c(x_start)
+        tran, pri = _lib.f32c(prior["transition_info"]), _lib.f32c(prior["trajectory_prior"])
+        if self.auto_normalize_data:
+            x0, tran, pri = ops.normalize(x0), ops.normalize(tran), ops.normalize(pri)
+        B = x0.shape[0]
+        if t is None:
+            t = torch.randint(0, self.timesteps, (B,), device=x0.device)
+        t = t.to(device=x0.device, dtype=torch.int64).contiguous()
+        if noise is None:
+            noise = torch.randn_like(x0)
+        noise = _lib.f32c(noise)
+        x, v = ops.q_sample(x0, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, want_v=self.objective == "pred_v")
+        cond = dict(maps_info=prior.get("maps_info"), transition_info=tran, trajectory_prior=pri)
+        model_out = self.model(x, t, cond)
+        target = {"pred_noise": noise, "pred_x0": x0, "pred_v": v}[self.objective]
+        rows, mean = ops.weighted_mse(model_out, target, t, self.loss_weight)
+        return (mean, rows) if return_rows else mean
 
     def forward(self, prior, trajectory_label, get_inter=False, **kwargs):
         if self.training:
-            raise NotImplementedError("the training loss (p_losses) is outside the accelerated sampling path; call .eval()")
+            return self.p_losses(prior, trajectory_label, **kwargs)
         return self.sample(prior, trajectory_label, return_all_timesteps=get_inter, **kwargs)
 
 
@@ -262,12 +306,20 @@ class TrajectoryRefiner(nn.Module):
             ddim_sampling_eta=cfg.ddim, auto_normalize_data=cfg.normalize, residual=cfg.residual)
 
     @torch.no_grad()
-    def generate(self, label, transition_info, trajectory_prior, maps_info, noise: Optional[torch.Tensor] = None):
+    def generate(self, label, transition_info, trajectory_prior, maps_info, noise: Optional[torch.Tensor] = None, **kwargs):
         condition = {"maps_info": maps_info, "transition_info": transition_info, "trajectory_prior": trajectory_prior}
-        return self.diffusion.sample(condition, label, noise=noise)
+        return self.diffusion.sample(condition, label, noise=noise, **kwargs)
 
-    def forward(self, label, transition_info, trajectory_prior, maps_info):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
+    @torch.no_grad()
+    def forward(self, label, transition_info, trajectory_prior, maps_info, t: Optional[torch.Tensor] = None,
+                noise: Optional[torch.Tensor] = None):
+        """-> (loss, logits): the diffusion loss of one chunk times ``trajectory_loss_rescale`` and, as in the reference
+        (TrajRefiner.py:100-121), all-zero ``logits`` of the label's shape."""
+        condition = {"maps_info": maps_info, "transition_info": transition_info, "trajectory_prior": trajectory_prior}
+        if not self.diffusion.training:
+            raise RuntimeError("TrajectoryRefiner.forward computes the loss: call .train() first (generate() samples)")
+        loss = self.diffusion(condition, label, t=t, noise=noise) * float(getattr(self.cfg, "trajectory_loss_rescale", 1.0))
+        return loss, torch.zeros_like(label)
 
 
 class DiffusionAugmentation(nn.Module):
@@ -293,31 +345,67 @@ class DiffusionAugmentation(nn.Module):
         self.diffusion = TrajectoryRefiner(config)
         self.init_x = nn.Parameter(torch.randn(self.frame_stack, self.trajectory_dim))
 
-    @torch.no_grad()
-    def generate(self, noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, **kwargs):
+    def _phase1(self, kwargs):
         if "trajectory_prior" in kwargs and "maps_info" in kwargs:
-            trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
-        else:
-            if self.str_model[0] is None:
-                raise ValueError("generate() needs either trajectory_prior/maps_info or a str_model for phase 1")
-            str_result = self.str_model[0].generate(**kwargs)
-            trajectory_prior, maps_info = str_result["traj_logits"], str_result["maps_info"]
+            return kwargs["trajectory_prior"], kwargs["maps_info"]
+        if self.str_model[0] is None:
+            raise ValueError("needs either trajectory_prior/maps_info or a str_model for phase 1")
+        str_result = self.str_model[0].generate(**kwargs)
+        return str_result["traj_logits"], str_result["maps_info"]
+
+    @torch.no_grad()
+    def generate(self, noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, seed: Optional[int] = None,
+                 row0: int = 0, **kwargs):
+        """-> {"traj_logits": (B, 80, 4) float32}.  ``noise``: (n_chunks, 1 + draws, B, fs, 4); None draws it on the device
+        (``seed`` / ``row0``: generator seed and global index of batch row 0, see the module docstring)."""
+        trajectory_prior, maps_info = self._phase1(kwargs)
         B, S = trajectory_prior.shape[:2]
         if S % self.frame_stack != 0:
             raise ValueError("Number of frames must be divisible by frame stack size")
         wrapper = self.diffusion.diffusion
         eng = wrapper.model.engine()
         eng.set_schedule(wrapper.schedule_rows())
-        n_chunks = S // self.frame_stack
         if noise is None:
-            noise = wrapper.make_noise((B, self.frame_stack, self.trajectory_dim), trajectory_prior.device, n_chunks)
+            eng.seed_from_torch(seed, row0)
         maps = _lib.f32c(maps_info) if self.map_cond else None
-        traj = eng.generate_a(maps, _lib.f32c(trajectory_prior), _lib.f32c(self.init_x), _lib.f32c(noise), self.frame_stack,
-                              wrapper.flags(), out=out)
+        traj = eng.generate_a(maps, _lib.f32c(trajectory_prior), _lib.f32c(self.init_x),
+                              _lib.f32c(noise) if noise is not None else None, self.frame_stack, wrapper.flags(), out=out)
         return {"traj_logits": traj}
 
-    def forward(self, return_dict=None, **kwargs):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path; use generate()")
+    @torch.no_grad()
+    def forward(self, return_dict=None, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
+        """The evaluation-time value of the training objective (DiffusionAugmentation.py:75-135), forward only: per chunk
+        one diffusion loss of the label chunk (label minus prior with ``residual``) conditioned on the prior chunk and on the
+        previous chunk's ``prediction`` -- which the reference's refiner returns as zeros, so chunks after the first see a
+        zero transition.  ``t`` (n_chunks, B) and ``noise`` (n_chunks, B, fs, 4) fix the random draws.
+        -> LTMOutput(loss, loss_items (n_chunks,), logits (B, 80, 4) zeros, pred_dict, trajectory_label)."""
+        trajectory_prior, maps_info = self._phase1(kwargs)
+        trajectory_label = kwargs.get("trajectory_label", None)
+        if trajectory_label is None:
+            raise ValueError("forward() needs trajectory_label")
+        trajectory_label = trajectory_label.to(trajectory_prior.device)
+        if self.residual:
+            trajectory_label = trajectory_label - trajectory_prior
+        B, S = trajectory_prior.shape[:2]
+        fs = self.frame_stack
+        if S % fs != 0:
+            raise ValueError("Number of frames must be divisible by frame stack size")
+        n_chunks = S // fs
+        label = _lib.f32c(trajectory_label).reshape(B, n_chunks, fs, -1)
+        prior = _lib.f32c(trajectory_prior).reshape(B, n_chunks, fs, -1)
+        transition = self.init_x[None].expand(B, *self.init_x.shape).contiguous()
+        self.diffusion.train()
+        losses, preds = [], []
+        for c in range(n_chunks):
+            l, prediction = self.diffusion(label[:, c].contiguous(), transition, prior[:, c].contiguous(), maps_info,
+                                           t=None if t is None else t[c], noise=None if noise is None else noise[c])
+            transition = prediction
+            losses.append(l.reshape(()))
+            preds.append(prediction)
+        final_predict = torch.stack(preds, dim=1).reshape(B, S, -1)
+        loss = torch.stack(losses)
+        return LTMOutput(loss=loss.mean(), loss_items=loss, logits=final_predict, pred_dict={"traj_logits": final_predict},
+                         trajectory_label=trajectory_label)
 
 
 def refiner_config(frame_stack: int = 10, diffusion_timesteps: int = 100, objective: str = "pred_noise",

@@ -146,7 +146,10 @@ def ddim_rows(b: Dict[str, torch.Tensor], objective: str, sampling_timesteps: in
         alpha, alpha_next = ac[t], ac[t_next]
         sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
         c = (1 - alpha_next - sigma ** 2).sqrt()
-        rows.append(_row(t, a0, a1, clamp, 1.0, b0, b1, c0=float(alpha_next.sqrt()), c2=float(c), c3=float(sigma), z_index=float(zi)))
+        # the reference draws a tensor at every such step even when sigma == 0 (so draw zi keeps its place in the order the
+        # reference consumes its generator), but a draw multiplied by zero is never read: it gets no index
+        rows.append(_row(t, a0, a1, clamp, 1.0, b0, b1, c0=float(alpha_next.sqrt()), c2=float(c), c3=float(sigma),
+                         z_index=float(zi) if float(sigma) != 0.0 else -1.0))
         zi += 1
     return rows
 

@@ -54,14 +54,18 @@ class DiffusionTransitionModel(nn.Module):
         return torch.randn(*lead, batch, self.cfg.frame_stack, self.cfg.x_shape[-1], device=device)
 
     @torch.no_grad()
-    def generate(self, xs, z, cond, prior, noise: Optional[torch.Tensor] = None):
+    def generate(self, xs, z, cond, prior, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, row0: int = 0):
         """xs (B, fs, 4) [shape only], z (B, fs, z_dim), cond = maps_info (B, 788, cond_dim), prior (B, fs, 4)
-        -> (z_next (B, fs, z_dim), x_next (B, fs, 4)).  ``noise``: (draws, B, fs, 4), default fresh N(0, 1)."""
+        -> (z_next (B, fs, z_dim), x_next (B, fs, 4)).  ``noise``: (draws, B, fs, 4); None draws it on the device with the
+        library's counter-based generator (``seed``, ``row0`` = global index of batch row 0)."""
         rows = self.schedule_rows()
         B = prior.shape[0]
         prior = _lib.f32c(prior)
         if noise is None:
-            noise = self.make_noise(B, prior.device)
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            fs, C = self.cfg.frame_stack, self.cfg.x_shape[-1]
+            noise = ops.randn(max(schedules.n_noise_draws(rows), 1), B, fs * C, seed, row0, device=prior.device).reshape(-1, B, fs, C)
         transition = ops.linear(_lib.f32c(z), self.z_emb.weight, self.z_emb.bias)
         condition = dict(maps_info=_lib.f32c(cond), transition_info=transition, trajectory_prior=prior)
         trajectory = prior.clone()
@@ -104,8 +108,8 @@ class StrDiffDiT(nn.Module):
         return xs * self.data_std.to(xs.device) + self.data_mean.to(xs.device)
 
     @torch.no_grad()
-    def generate(self, noise: Optional[torch.Tensor] = None, **kwargs):
-        """-> {"traj_logits": (B, 80, 4) float32}.  ``noise``: (n_chunks, draws, B, fs, 4)."""
+    def generate(self, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, row0: int = 0, **kwargs):
+        """-> {"traj_logits": (B, 80, 4) float32}.  ``noise``: (n_chunks, draws, B, fs, 4); None draws it on the device."""
         if "trajectory_prior" in kwargs and "maps_info" in kwargs:
             trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
         else:
@@ -122,8 +126,8 @@ class StrDiffDiT(nn.Module):
         conditions = _lib.f32c(trajectory_prior).clone()
         conditions[:, :1] = 0.0                                       # StrDiffDiT.py:182
         conditions = conditions.reshape(B, n_chunks, self.frame_stack, C)
-        if noise is None:
-            noise = self.transition_model.make_noise(B, conditions.device, n_chunks)
+        if noise is None and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         if self.learnable_init_z:
             z = self.init_z[None].expand(B, *self.z_shape).contiguous()
         else:
@@ -131,7 +135,9 @@ class StrDiffDiT(nn.Module):
         xs = torch.empty(B, self.frame_stack, C, device=conditions.device)      # shape only
         preds = []
         for c in range(n_chunks):
-            z, x_next = self.transition_model.generate(xs, z, maps_info, conditions[:, c].contiguous(), noise=noise[c])
+            z, x_next = self.transition_model.generate(xs, z, maps_info, conditions[:, c].contiguous(),
+                                                       noise=None if noise is None else noise[c],
+                                                       seed=None if noise is not None else seed + c, row0=row0)
             preds.append(x_next)
         out = torch.stack(preds, dim=1).reshape(B, S, C)
         return {"traj_logits": self._unnormalize_x(out).to(torch.float32)}

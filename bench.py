@@ -6,21 +6,27 @@
 Workload (BASELINE.json configs[1]): the strDiffDiT-style refiner -- encoder/decoder Transformer denoiser,
 d=32, 8 heads, 2 encoder + 4 decoder layers, frame_stack 10 (8 chunks of 10 trajectory tokens, 809
 conditioning tokens), in-repo DDIM sampler 50 of 100 steps (eta 0, cosine schedule, pred_noise), bf16 MFMA GEMMs
-(split operands by default, see --precision) / fp32 state, B = 4096 scenarios per GPU, random-init weights, synthetic nuPlan-shaped conditioning
-already resident in HBM.  One "step" = one generate() pass over the batch: 8 chunks x 50 denoiser calls +
-scheduler updates, replayed from one hipGraph, plus (N > 1) the all-gather of the sampled trajectories.
+(split operands by default, see --precision) / fp32 state, B = 1024 scenarios per GPU (the configured batch), random-init
+weights, synthetic nuPlan-shaped conditioning already resident in HBM.  One "step" = one generate() pass over the batch:
+8 chunks x 50 denoiser calls + scheduler updates, replayed from one hipGraph, plus (N > 1) the all-gather of the sampled
+trajectories.
 
-With N > 1 the driver launches one process per GPU (torch.distributed.run); every rank samples its own B
-scenarios (weak scaling) and the only collective is the final all-gather.
+With N > 1 there is one process per GPU; every rank samples its own B scenarios (weak scaling) and the only collective is
+the final all-gather.  Started by torch.distributed.run (RANK / WORLD_SIZE in the environment) the process is one rank;
+started plainly with --gpus N > 1 it launches the N ranks itself (a fresh torch.distributed.run child, before this process
+touches a GPU) and relays rank 0's line.
 
-Rank 0 prints one JSON line.  ``roofline`` describes the kernel that dominates the step (measured live with
-events on the launch stream); ``cpu_baseline`` times the CPU oracle on a bounded sample of the same workload.
+Rank 0 prints one JSON line.  ``roofline`` describes the kernel that dominates the step (measured live with events on the
+launch stream); ``cpu_baseline`` times the CPU oracle on a bounded sample of BASELINE.json configs[0]; ``knee`` is the same
+workload at 4096 scenarios per GPU (where every kernel fills the chip); ``dit_gemm`` is the dominant GEMM of the scaled DiT
+decoder (M = 256 x 80 tokens, N = 4096, K = 1024) timed live, the second half of the metric.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,12 +49,12 @@ def build_model(dev, precision="bf16"):
     return da.to(dev).eval()
 
 
-def make_inputs(B, row0, dev):
+def make_inputs(B, row0, dev, n_noise):
+    """Conditioning and noise of B scenarios whose global indices start at row0 (a shard regenerates exactly its rows)."""
     from autodiffusion_amd import synth
     maps = synth.maps_info(B, 7, row0).to(dev)
     prior = synth.trajectory_prior(B, 7, row0).to(dev)
-    n_draws = N_SAMPLE if N_SAMPLE < N_TRAIN else N_TRAIN      # DDIM (eta 0) reads only the first; DDPM one per step
-    noise = synth.noise(B, (80 // FS, n_draws), (FS, 4), 1234, row0).to(dev)
+    noise = synth.noise(B, (80 // FS, n_noise), (FS, 4), 1234, row0).to(dev)      # the initial draw + what the schedule reads
     return maps, prior, noise
 
 
@@ -167,17 +173,22 @@ def bench_dit(args, dev):
 
 
 def cpu_baseline():
-    """The fp32 CPU oracle on one chunk (of 8) of a 16-scenario batch, all 50 DDIM steps."""
-    from autodiffusion_amd import synth
+    """BASELINE.json configs[0] on the host cores with the fp32 CPU oracle: B = 16, frame_stack 10, 100-step DDPM (cosine,
+    pred_noise).  Bounded sample: ONE of the 8 chunks with all 100 steps on every allowed thread (the 8 chunks are
+    sequential and cost the same, so the whole job is 8x that), plus 10 steps of the same chunk on one thread."""
+    from autodiffusion_amd import refiner, synth
     from oracle import nets, sampling, schedules as osched
-    B = 16
-    da = build_model("cpu", "fp32")
+    B, fs, N = 16, 10, 100
+    cfg = refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective="pred_noise", beta_schedule="cosine", precision="fp32")
+    da = refiner.DiffusionAugmentation(cfg)
+    synth.reference_init_(da, 11)
     sd = {k[len("diffusion.diffusion.model."):]: v.detach().float() for k, v in da.state_dict().items()
           if k.startswith("diffusion.diffusion.model.")}
     maps = synth.maps_info(B, 7)
-    prior = synth.trajectory_prior(B, 7)[:, :FS].contiguous()
-    noise = synth.noise(B, (N_SAMPLE,), (FS, 4), 1234)
-    bufs = osched.buffers("cosine", N_TRAIN, "pred_noise")
+    prior = synth.trajectory_prior(B, 7)[:, :fs].contiguous()
+    noise = synth.noise(B, (N,), (fs, 4), 1234)
+    bufs = osched.buffers("cosine", N, "pred_noise")
+    n_chunks = 80 // fs
 
     def fn(x, t, tra_n, pri_n):
         tt = torch.full((x.shape[0],), int(t), dtype=torch.long)
@@ -186,19 +197,89 @@ def cpu_baseline():
     with torch.no_grad():
         fn(noise[0], 5, prior, prior)     # warm-up call
         t0 = time.perf_counter()
-        sampling.refiner_sample(fn, bufs, "pred_noise", prior * 0.5, prior, noise, n_sample=N_SAMPLE)
+        sampling.refiner_sample(fn, bufs, "pred_noise", prior * 0.5, prior, noise)      # DDPM: all 100 steps of one chunk
         dt = time.perf_counter() - t0
-    n_chunks = 80 // FS
+        torch.set_num_threads(1)
+        try:
+            fn(noise[0], 5, prior, prior)
+            t0 = time.perf_counter()
+            for k in range(10):
+                fn(noise[k], 50 + k, prior, prior)
+            dt1 = (time.perf_counter() - t0) / 10
+        finally:
+            torch.set_num_threads(threads)
     return {"value": round(B / (dt * n_chunks), 4), "unit": "trajectories/s", "cores": threads, "kind": "port",
-            "sample": f"fp32 CPU oracle, B=16, 1 of {n_chunks} chunks x {N_SAMPLE} DDIM steps ({dt:.1f} s), scaled by {n_chunks}"}
+            "sample": f"fp32 CPU oracle on configs[0] (B=16, frame_stack 10, 100-step DDPM): 1 of {n_chunks} chunks x {N} steps timed "
+                      f"({dt:.1f} s on {threads} threads), whole job = {n_chunks}x",
+            "ms_per_denoiser_call": round(dt / N * 1e3, 1),
+            "one_thread": {"value": round(B / (dt1 * N * n_chunks), 4), "cores": 1, "ms_per_denoiser_call": round(dt1 * 1e3, 1),
+                           "sample": "10 denoiser calls of the same chunk on 1 thread, scaled to 8 chunks x 100 steps"}}
+
+
+def dit_gemm(dev):
+    """The dominant GEMM of the scaled DiT decoder (BASELINE.json configs[4]: hidden 1024, 256 scenarios x 80 tokens): the MLP /
+    FFN expansion M = 20480, N = 4096, K = 1024 through the library's staged entry point, both bf16 operand modes, timed with
+    events on the launch stream.  ``tflops`` is the product's 2 M N K per second; ``executed_tflops`` counts the MFMAs the
+    kernel issues (three per product with split operands) and ``frac`` prices that against the dense bf16 MFMA peak."""
+    from autodiffusion_amd import ops
+    M, N, K = 20480, 4096, 1024
+    x = torch.randn(M, K, device=dev)
+    w32 = torch.randn(N, K, device=dev) * 0.02
+    bias = torch.zeros(N, device=dev)
+    out = {"shape": {"M": M, "N": N, "K": K}, "peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+    for prec, mult in (("bf16x3", 3), ("bf16", 1)):
+        w = ops.prepare_weight(w32, prec)
+        ws = torch.empty(ops.linear_stage_bytes(M, N, K, prec) + 64, dtype=torch.uint8, device=dev)
+        t = time_kernel(lambda k: [ops.linear(x, w, bias, precision=prec, prepared_n=N, workspace=ws) for _ in range(k)], 20)
+        tf = 2.0 * M * N * K / t / 1e12
+        out[prec] = {"us": round(t * 1e6, 1), "tflops": round(tf, 1), "executed_tflops": round(tf * mult, 1),
+                     "frac": round(tf * mult / MFMA_BF16_PEAK_TFLOPS, 4)}
+    return out
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a fresh child (never from a process that initialised a GPU) and
+    relay its output; rank 0 of the child prints the JSON line."""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """No GPU: the launch, sharding and gather logic of the real run with gloo on the CPU.  Every rank "samples" its shard of
+    a ragged total as a function of the global row index; the gathered tensor must equal the single-process one."""
+    import torch.distributed as dist
+    from autodiffusion_amd import synth
+    from autodiffusion_amd.distributed import RowGatherer, shard_range
+    if world > 1:
+        dist.init_process_group("gloo")
+    total = 5 * world + (1 if world > 1 else 0)              # ragged on purpose
+    lo, hi = shard_range(total, rank, world)
+    gather = RowGatherer(total, (80, 4), "cpu")
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 1)):
+        full = gather.gather(synth.noise(hi - lo, (), (80, 4), 1234, row0=lo))
+    dt = time.perf_counter() - t0
+    ok = bool(torch.equal(full, synth.noise(total, (), (80, 4), 1234)))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU): launch + shard + gather", "value": round(total * args.steps / dt, 2),
+                          "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathered_equals_single_process": ok,
+                          "config": {"workload": "gloo dry run", "global_batch": total, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 4096 for the refiner)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 1024 for the refiner, the configured batch)")
     ap.add_argument("--workload", default="refiner", choices=["refiner"] + sorted(DIT_WORKLOADS),
                     help="refiner = the headline configuration; the DiT decoder workloads run on one GPU only")
     ap.add_argument("--frame-stack", type=int, default=0, help="refiner: points per chunk (default 10; 80 = whole trajectory)")
@@ -207,18 +288,28 @@ def main():
     ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the knee and dit_gemm measurements (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise launch, sharding and gather with gloo on the CPU")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))                  # nothing below ran in this process: no GPU was touched
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    if args.dry_run:
+        raise SystemExit(dry_run(args, rank, world))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     global FS, N_TRAIN, N_SAMPLE, L_COND
     FS, N_TRAIN, N_SAMPLE = args.frame_stack or FS, args.n_train or N_TRAIN, args.n_sample or N_SAMPLE
@@ -228,36 +319,45 @@ def main():
             raise SystemExit("the DiT workloads are single-GPU measurements")
         return bench_dit(args, dev)
 
-    from autodiffusion_amd.distributed import all_gather_rows
-    B = args.batch or 4096
+    from autodiffusion_amd import schedules
+    from autodiffusion_amd.distributed import RowGatherer
     da = build_model(dev, args.precision)
-    maps, prior, noise = make_inputs(B, rank * B, dev)
-    out = torch.empty(B, 80, 4, device=dev)
-    total = B * world
+    n_noise = 1 + schedules.n_noise_draws(da.diffusion.diffusion.schedule_rows())
 
-    def step():
-        da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
-        return all_gather_rows(out, total) if world > 1 else out
+    def measure(B, steps, warmup):
+        """K timed generate() passes (+ gather) over B scenarios per rank; returns (seconds, step function, gathered rows)."""
+        maps, prior, noise = make_inputs(B, rank * B, dev, n_noise)
+        out = torch.empty(B, 80, 4, device=dev)
+        gatherer = RowGatherer(B * world, (80, 4), dev)
 
-    def fence():
-        torch.cuda.synchronize()
+        def step():
+            da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
+            return gatherer.gather(out)               # enqueued behind the sampling graph on the same stream
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(max(warmup, 1)):      # the first call captures the graph
+            gathered = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gathered = step()
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        assert gathered.shape[0] == B * world and bool(torch.isfinite(gathered).all())
+        return dt, step
 
-    for _ in range(max(args.warmup, 1)):      # the first call captures the graph
-        gathered = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert gathered.shape[0] == total and bool(torch.isfinite(gathered).all())
+    B = args.batch or 1024
+    total = B * world
+    dt, step = measure(B, args.steps, args.warmup)
 
     if rank == 0:
         line = {
@@ -269,15 +369,24 @@ def main():
                                    + ", random init, synthetic nuPlan-shaped conditioning",
                        "batch_per_gpu": B, "global_batch": total, "denoiser_calls_per_step": (80 // FS) * N_SAMPLE,
                        "parallelism": f"dp{world}",
-                       "precision": {"bf16x3": "bf16 MFMA on split (hi+lo) operands, f32 accumulate; trajectory path and scheduler f32",
+                       "precision": {"bf16x3": "bf16 MFMA on split (hi+lo) operands, 3 MFMAs per product, f32 accumulate; trajectory path and scheduler f32",
                                      "bf16": "bf16 MFMA operands, f32 accumulate; trajectory path and scheduler f32",
                                      "fp32": "f32 MFMA"}[args.precision]},
         }
-        if world == 1:
-            if FS == 10:                                      # the fused kernels the roofline entry describes need T + 1 <= 16
-                line["roofline"] = roofline(da, B, step)
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline()
+        if world == 1 and FS == 10:                              # the fused kernels the roofline entry describes need T + 1 <= 16
+            line["roofline"] = roofline(da, B, step)
+    if world == 1 and not args.no_extras and not args.batch and FS == 10:
+        B2 = 4096
+        dt2, step2 = measure(B2, 3, 1)
+        knee = {"batch_per_gpu": B2, "value": round(B2 * 3 / dt2, 2), "unit": "trajectories/s", "ms_per_step": round(dt2 / 3 * 1e3, 3),
+                "note": "same workload at 4x the configured batch: every per-step kernel fills the 256 CUs"}
+        r2 = roofline(da, B2, step2)
+        knee["roofline_frac"], knee["launch_us"] = r2["frac"], r2["launch_us"]
+        line["knee"] = knee
+        line["dit_gemm"] = dit_gemm(dev)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

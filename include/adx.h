@@ -154,6 +154,11 @@ int adx_engine_destroy(adx_engine* e);
 int adx_engine_set_tensor(adx_engine* e, const char* name, const float* data, const int64_t* shape_host, int ndim);
 /* Verify that every parameter the configured model needs is present with the right shape. */
 int adx_engine_finalize(adx_engine* e);
+/* Call order: adx_engine_create, adx_engine_set_tensor for every parameter, adx_engine_finalize, adx_engine_set_schedule (sampling
+ * calls only), then any number of denoise / sample / generate calls.  Parameters may be replaced at any time with
+ * adx_engine_set_tensor followed by adx_engine_finalize: finalize rebuilds every table derived from the weights (the schedule
+ * set earlier stays in force) and drops the captured graphs. */
+
 /* (Re)allocate the activation workspace for batches up to max_batch rows. */
 int adx_engine_reserve(adx_engine* e, int max_batch);
 int64_t adx_engine_workspace_bytes(const adx_engine* e);
@@ -169,12 +174,34 @@ int adx_denoise_a(adx_engine* e, int B, const float* x, const int64_t* t, const 
 int adx_denoise_dit(adx_engine* e, int B, const float* x, const int64_t* t, const float* state, float* out,
                     void* stream);
 
+/* No counterpart in the reference (its samplers call torch.randn / randn_like: TrajRefiner.py:319,311,367): seed and global index
+ * of batch row 0 for sampling calls that pass noise == NULL.  Such calls draw their noise on the device, inside the captured
+ * graph: Philox4x32-10 keyed by `seed`, counter = (row0 + batch row, chunk * (1 + draws) + draw, element / 4), Box-Muller.  A row's
+ * noise therefore does not depend on which shard of the batch it runs in.  Only the draws the schedule reads are generated. */
+int adx_engine_set_noise_seed(adx_engine* e, uint64_t seed, int64_t row0);
+/* The same generator as an operator: out[n_lead][B][row_len]; ctl_scratch = 16 bytes of device memory. */
+int adx_op_randn(float* out, int n_lead, int B, int row_len, uint64_t seed, int64_t row0, uint64_t* ctl_scratch, void* stream);
+
+/* No counterpart in the reference: number of hipGraph captures this engine has made.  A sampling call captures once per
+ * (shape, flags, schedule); callers whose buffer addresses change from call to call are served from engine-owned staging
+ * buffers (inputs copied in, result copied out on `stream`), so they do not capture again either. */
+int64_t adx_engine_capture_count(const adx_engine* e);
+
+/* DiffusionWrapper.q_sample / predict_v (TrajRefiner.py:250-254, 408-415): xt = sqrt_acp[t] x0 + sqrt_1m_acp[t] noise with one
+ * timestep per row of row_len values; v (nullable) = sqrt_acp[t] noise - sqrt_1m_acp[t] x0. */
+int adx_op_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp,
+                    float* xt, float* v, int n_rows, int row_len, void* stream);
+/* The loss of DiffusionWrapper.p_losses (TrajRefiner.py:448-452): loss_rows[b] = weight[t[b]] * mean((out[b] - target[b])^2),
+ * loss_mean[0] (nullable) = mean over rows. */
+int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows,
+                        float* loss_mean, int n_rows, int row_len, void* stream);
+
 /* Per-step coefficient table of the sampler (host memory), in execution order. */
 int adx_engine_set_schedule(adx_engine* e, const adx_step_coef* steps_host, int n_steps);
 
 /* DiffusionWrapper.sample for one chunk -- TrajRefiner.py:315-386 (p_sample_loop / ddim_sample / sample).
- * transition/prior are RAW (un-normalised) [B][P][prior_dim]; noise[(1+n_draws)][B][T][in_dim];
- * out[B][T][in_dim].  trace_x / trace_out (nullable) receive x_t and the model output of every step,
+ * transition/prior are RAW (un-normalised) [B][P][prior_dim]; noise[(1+n_draws)][B][T][in_dim] (NULL: drawn on the device, see
+ * adx_engine_set_noise_seed); out[B][T][in_dim].  trace_x / trace_out (nullable) receive x_t and the model output of every step,
  * [n_steps][B][T][in_dim] each. */
 int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transition, const float* prior,
                  const float* noise, int n_noise, float* out, float* trace_x, float* trace_out, unsigned flags,
@@ -184,7 +211,7 @@ int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transitio
  * and models/backbone/ExplicitDiT.py:139-198 (flattened layout, config in_dim = frame_stack*4):
  * prior_full[B][S][4] is cut into S/frame_stack chunks, each sampled with the previous chunk's output as
  * transition_info (init_x[frame_stack][4] for the first), results re-assembled into out[B][S][4].
- * noise[n_chunks][n_noise][B][T][in_dim]. */
+ * noise[n_chunks][n_noise][B][T][in_dim] (NULL: drawn on the device, see adx_engine_set_noise_seed). */
 int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
                    const float* init_x, const float* noise, int n_noise, float* out, unsigned flags, void* stream);
 
@@ -204,8 +231,8 @@ int adx_engine_profile_read(adx_engine* e, int stage, double* total_ms, int* cou
 int adx_debug_stage_a(adx_engine* e, int B, int stage, int iters, void* stream);
 
 /* DiffusionWrapper.sample_forward / p_sample_loop -- models/diffusion_loss/diffusion_decoder.py:377-446.
- * state[B][S][d_model]; noise[n_noise][B][S][4] (may be NULL with ADX_FLAG_INIT_ZERO and a noise-free
- * schedule); out[B][S][4] is de-normalised when ADX_FLAG_NORMALIZE is set. */
+ * state[B][S][d_model]; noise[n_noise][B][S][4] (NULL: none with ADX_FLAG_INIT_ZERO, otherwise drawn on the device, see
+ * adx_engine_set_noise_seed); out[B][S][4] is de-normalised when ADX_FLAG_NORMALIZE is set. */
 int adx_sample_dit(adx_engine* e, int B, const float* state, const float* noise, int n_noise, float* out,
                    unsigned flags, void* stream);
 

@@ -4,6 +4,7 @@ In-repo diffusion maths: transformer4planning/models/diffusion_loss/TrajRefiner.
   :238-313 (x0 / eps conversions, posterior, p_sample), :315-333 (p_sample_loop),
   :335-376 (ddim_sample), :378-386 (sample + residual);
 decoder twin: transformer4planning/models/diffusion_loss/diffusion_decoder.py:377-479;
+evaluation-time loss: TrajRefiner.py:408-452, DiffusionAugmentation.py:75-135, diffusion_decoder.py:346-365;
 normalisation: transformer4planning/models/utils.py:56-80;
 chunk loop: transformer4planning/models/backbone/DiffusionAugmentation.py:137-195;
 flattened-chunk wrapper: transformer4planning/models/backbone/ExplicitDiT.py:139-210 with
@@ -149,7 +150,86 @@ def refiner_generate(denoise_cond: Callable, b, objective: str, maps_unused, pri
     return torch.stack(preds).permute(1, 0, 2, 3).reshape(B, S, C)
 
 
+# ------------------------------------------------------------------ evaluation-time value of the training loss
+def refiner_loss(denoise_cond: Callable, b: Dict[str, np.ndarray], objective: str, transition_info, trajectory_prior, x_start,
+                 t: torch.Tensor, noise: torch.Tensor, auto_normalize: bool = True) -> torch.Tensor:
+    """DiffusionWrapper.p_losses (TrajRefiner.py:417-452) with the random draws supplied: ``t`` (B,) int64, ``noise`` like
+    ``x_start``.  ``denoise_cond(x, t_tensor, transition_n, prior_n) -> out`` (no dropout).  Returns the scalar loss."""
+    norm = normalize if auto_normalize else (lambda v: v)
+    x0, tra_n, pri_n = norm(x_start), norm(transition_info), norm(trajectory_prior)
+    ext = lambda key: torch.as_tensor(b[key], dtype=torch.float32)[t].reshape(-1, *([1] * (x0.dim() - 1)))  # noqa: E731
+    sa, s1 = ext("sqrt_alphas_cumprod"), ext("sqrt_one_minus_alphas_cumprod")
+    x = sa * x0 + s1 * noise
+    out = denoise_cond(x, t, tra_n, pri_n)
+    target = {"pred_noise": noise, "pred_x0": x0, "pred_v": sa * noise - s1 * x0}[objective]
+    loss = ((out - target) ** 2).reshape(x0.shape[0], -1).mean(dim=1)
+    return (loss * torch.as_tensor(b["loss_weight"], dtype=torch.float32)[t]).mean()
+
+
+def refiner_forward(denoise_cond: Callable, b, objective: str, prior_full, label_full, init_x, t, noise, frame_stack: int,
+                    residual: bool = False, auto_normalize: bool = True, rescale: float = 1.0):
+    """DiffusionAugmentation.forward (DiffusionAugmentation.py:75-135), loss part: chunk c is scored with the prior chunk,
+    the label chunk (label - prior with ``residual``) and a transition that is ``init_x`` for chunk 0 and ZERO afterwards
+    (TrajectoryRefiner.forward returns all-zero logits as its "prediction", TrajRefiner.py:115-121).
+    ``t`` (n_chunks, B), ``noise`` (n_chunks, B, fs, 4).  Returns (mean loss, per-chunk losses)."""
+    B, S, C = prior_full.shape
+    n_chunks = S // frame_stack
+    label = label_full - prior_full if residual else label_full
+    lab = label.reshape(B, n_chunks, frame_stack, C)
+    pri = prior_full.reshape(B, n_chunks, frame_stack, C)
+    transition = init_x[None].expand(B, frame_stack, C)
+    losses = []
+    for c in range(n_chunks):
+        losses.append(refiner_loss(denoise_cond, b, objective, transition, pri[:, c], lab[:, c], t[c], noise[c], auto_normalize) * rescale)
+        transition = torch.zeros(B, frame_stack, C)
+    losses = torch.stack(losses)
+    return losses.mean(), losses
+
+
+# ------------------------------------------------------------------ counter-based Gaussian noise (the library's generator)
+def philox4x32_10(counter, key0: int, key1: int):
+    """Four uint32 words (as uint64 arrays) per counter {c0, c1, c2, c3} (arrays or ints) under the 64-bit key {key0, key1}."""
+    c = [np.asarray(v, dtype=np.uint64) for v in counter]
+    k0, k1 = np.uint64(key0), np.uint64(key1)
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & MASK, p0 & MASK]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c
+
+
+def philox_randn(n_lead: int, batch: int, row_len: int, seed: int, row0: int = 0) -> np.ndarray:
+    """Philox4x32-10 (Salmon et al. 2011) + Box-Muller, as the device generator defines it: element e of batch row b under
+    leading index l comes from counter (row0 + b [64 bit], l, e // 4), key = seed; words (0,1) -> elements 4q, 4q+1 and
+    words (2,3) -> 4q+2, 4q+3 with u1 = ((w >> 8) + 1) 2^-24, u2 = (w' >> 8) 2^-24, z = sqrt(-2 ln u1) (cos, sin)(2 pi u2).
+    No counterpart in the reference (it calls torch.randn)."""
+    quads = (row_len + 3) // 4
+    l, bb, q = np.meshgrid(np.arange(n_lead, dtype=np.uint64), np.arange(batch, dtype=np.uint64), np.arange(quads, dtype=np.uint64),
+                           indexing="ij")
+    grow = bb + np.uint64(row0)
+    c = philox4x32_10([grow & np.uint64(0xFFFFFFFF), grow >> np.uint64(32), l, q], seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    out = np.empty((n_lead, batch, quads * 4), dtype=np.float64)
+    for j in (0, 1):
+        u1 = ((c[2 * j] >> np.uint64(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+        u2 = (c[2 * j + 1] >> np.uint64(8)).astype(np.float64) * 2.0 ** -24
+        r = np.sqrt(-2.0 * np.log(u1))
+        out[..., 2 * j::4] = r * np.cos(2.0 * np.pi * u2)
+        out[..., 2 * j + 1::4] = r * np.sin(2.0 * np.pi * u2)
+    return out[..., :row_len].astype(np.float32)
+
+
 # ------------------------------------------------------------------ decoder twin (DiT path)
+def twin_loss(denoise: Callable, b: Dict[str, np.ndarray], label, t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """DiffusionWrapper.train_forward of the decoder twin (diffusion_decoder.py:346-365) with the draws supplied: the
+    element-wise squared error of the noise estimate at x_t = q_sample(normalize(label), t, noise)."""
+    x0 = normalize(label)
+    ext = lambda key: torch.as_tensor(b[key], dtype=torch.float32)[t].reshape(-1, 1, 1)  # noqa: E731
+    x = ext("sqrt_alphas_cumprod") * x0 + ext("sqrt_one_minus_alphas_cumprod") * noise
+    return (denoise(x, t) - noise) ** 2
+
+
+
 def twin_sample(denoise: Callable, b: Dict[str, np.ndarray], shape, noise: Optional[torch.Tensor],
                 determin: bool = True, max_action: float = 100.0):
     """diffusion_decoder.py:385-446.  Returns (denormalised trajectory, total_cls).

@@ -362,15 +362,154 @@ def g11_select_modes():
     save("g11_select_modes", **out)
 
 
+# ----------------------------------------------------------------------------- G12: the benchmark configurations at their own sizes
+def _refiner(fs, N, obj="pred_noise", sched="cosine", residual=False, init="reference"):
+    cfg = SimpleNamespace(trajectory_dim=4, frame_stack=fs, n_maps_token=788, maps_dim=256, map_cond=True,
+                          beta_schedule=sched, diffusion_timesteps=N, objective=obj, ddim=0.0,
+                          normalize=True, residual=residual, trajectory_loss_rescale=1.0)
+    refiner = ref_tr.TrajectoryRefiner(cfg)
+    if init == "reference":
+        synth.reference_init_(refiner, WSEED)        # N(0, 0.02) matrices, zero biases: the reference's own initialisation
+    else:
+        synth.fill_module_(refiner, WSEED)
+    return refiner.eval()
+
+
+def g12_configs():
+    out = {}
+    B = 2
+    maps = synth.maps_info(B, ISEED)
+    prior = synth.trajectory_prior(B, ISEED)
+    # C1: frame_stack 10, 100-step ancestral DDPM (cosine, pred_noise), 8 chunks
+    fs, N = 10, 100
+    refiner = _refiner(fs, N)
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    nz = synth.noise(B, (80 // fs, N), (fs, 4), NSEED)
+    prior_c = prior.reshape(B, 80 // fs, fs, 4).permute(1, 0, 2, 3)
+    transition = init_x[None].expand(B, fs, 4)
+    preds = []
+    for c in range(80 // fs):
+        with noise_queue([nz[c, 0]] + [nz[c, 1 + i] for i in range(N - 1)]) as q:
+            pred = refiner.generate(torch.zeros(B, fs, 4), transition, prior_c[c], maps)
+            assert not q
+        transition = pred
+        preds.append(pred)
+    out["c1_fs10_ddpm100_traj"] = torch.stack(preds).permute(1, 0, 2, 3).reshape(B, 80, 4)
+    # C3: whole trajectory (frame_stack 80), in-repo DDIM 10 of 100 (eta 0)
+    fs, N, ns = 80, 100, 10
+    refiner = _refiner(fs, N)
+    rec = Recorder(refiner.diffusion.model)         # most of the final samples sit on the +-300 clamp: keep the per-step outputs too
+    w = ref_tr.DiffusionWrapper(rec, timesteps=N, sampling_timesteps=ns, objective="pred_noise",
+                                beta_schedule="cosine", ddim_sampling_eta=0.0, auto_normalize_data=True, residual=False).eval()
+    assert w.is_ddim_sampling
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    nz = synth.noise(B, (1, ns), (fs, 4), NSEED)
+    with noise_queue([nz[0, 0]] + [nz[0, 1 + i] for i in range(ns - 1)]) as q, torch.no_grad():
+        cond = dict(maps_info=maps, transition_info=init_x[None].expand(B, fs, 4).clone(), trajectory_prior=prior.clone())
+        out["c3_fs80_ddim10of100_traj"] = w(cond, torch.zeros(B, fs, 4))
+        assert not q
+    out["c3_fs80_ddim10of100_x"] = torch.stack(rec.xs)
+    out["c3_fs80_ddim10of100_model_out"] = torch.stack(rec.outs)
+    # C4: DiT / MM-DiT d=256 L=4 h=8, 16 samples of one scenario, 10 DDPM steps.  The reference's own mc_num > 1 branch fails on a
+    # shape mismatch of its score bookkeeping, so the 16 samples run as 16 batch rows of the single-sample stochastic path
+    # (same arithmetic per row; repeat_interleave of the state is what that branch does, diffusion_decoder.py:416).
+    mc, N = 16, 10
+    for backbone in ("DiT", "MM-DiT"):
+        dec = ref_dd.DiffusionDecoder(dit_config(256, 4, 8, backbone, n=N))
+        synth.fill_module_(dec, WSEED)
+        dec = dec.float().eval()
+        state = torch.repeat_interleave(synth.hidden_state(1, 256, ISEED), mc, dim=0)
+        nz = synth.noise(mc, (N + 1,), (80, 4), NSEED)
+        with torch.no_grad(), noise_queue([nz[0]] + [nz[1 + i] for i in range(N)]) as q:
+            out[f"c4_{backbone}_mc16"] = dec.model(state, batch_size=mc, determin=False)
+            assert not q
+    # C5: one denoiser call at hidden 1024, 16 heads (connect_dim 1600), 2 blocks (1 for MM-DiT: 134 M parameters per block)
+    for backbone, L in (("DiT", 2), ("MM-DiT", 1)):
+        m = build_dit(dit_config(1024, L, 16, backbone))
+        x = synth.noise(B, (), (80, 4), NSEED)
+        state = synth.hidden_state(B, 1024, ISEED)
+        t = torch.tensor([7, 150], dtype=torch.long)
+        with torch.no_grad():
+            out[f"c5_{backbone}_d1024_out"] = m(x, t, state)
+        out["c5_t"] = t
+        del m
+    save("g12_configs", **out)
+
+
+# ----------------------------------------------------------------------------- G13: evaluation-time loss
+@contextlib.contextmanager
+def fixed_randint(values):
+    """Replace torch.randint by pops from ``values`` (the timesteps p_losses draws)."""
+    q = list(values)
+    real = torch.randint
+
+    def randint(*a, **kw):
+        return q.pop(0).clone()
+    torch.randint = randint
+    try:
+        yield q
+    finally:
+        torch.randint = real
+
+
+def g13_forward_loss():
+    """DiffusionAugmentation.forward's loss (DiffusionAugmentation.py:75-135) driven around the reference's own
+    TrajectoryRefiner.forward, with the timesteps and noise of p_losses supplied and dropout switched off (the wrapper is in
+    train mode so that it takes the loss branch; the denoiser inside it is in eval mode)."""
+    out = {}
+    B = 2
+    maps = synth.maps_info(B, ISEED)
+    prior = synth.trajectory_prior(B, ISEED)
+    label = prior + synth.noise(B, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    out["label"] = label
+    for tag, fs, N, obj, sched, residual in (("fs10_eps", 10, 100, "pred_noise", "cosine", False),
+                                             ("fs10_x0_res", 10, 10, "pred_x0", "sigmoid", True),
+                                             ("fs80_v", 80, 50, "pred_v", "cosine", False)):
+        refiner = _refiner(fs, N, obj, sched, residual, init="seeded")
+        refiner.train()
+        refiner.diffusion.model.eval()                     # no dropout inside the denoiser
+        init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+        n_chunks = 80 // fs
+        g = np.random.default_rng(17)
+        t = torch.from_numpy(g.integers(0, N, size=(n_chunks, B)).astype(np.int64))
+        nz = synth.noise(B, (n_chunks,), (fs, 4), NSEED + 2)
+        lab = (label - prior if residual else label).reshape(B, n_chunks, fs, 4).permute(1, 0, 2, 3)
+        pri = prior.reshape(B, n_chunks, fs, 4).permute(1, 0, 2, 3)
+        transition = init_x[None].expand(B, fs, 4)
+        losses = []
+        with torch.no_grad():
+            for c in range(n_chunks):
+                with noise_queue([nz[c]]) as q, fixed_randint([t[c]]) as qt:
+                    l, prediction = refiner(lab[c], transition, pri[c], maps)
+                    assert not q and not qt
+                transition = prediction
+                losses.append(l)
+        out[f"{tag}_t"] = t
+        out[f"{tag}_loss_items"] = torch.stack(losses)
+        out[f"{tag}_loss"] = torch.stack(losses).mean()
+    # decoder twin: element-wise squared error of one train_forward call
+    for backbone in ("DiT", "MM-DiT"):
+        dec = ref_dd.DiffusionDecoder(dit_config(64, 2, 4, backbone, n=10))
+        synth.fill_module_(dec, WSEED)
+        dec = dec.float()
+        dec.train()
+        dec.model.model.eval()
+        state = synth.hidden_state(B, 64, ISEED)
+        t = torch.tensor([3, 8], dtype=torch.long)
+        nz = synth.noise(B, (), (80, 4), NSEED + 2)
+        with torch.no_grad(), noise_queue([nz]) as q, fixed_randint([t]) as qt:
+            loss, logits = dec(label, state)
+            assert not q and not qt
+        out[f"twin_{backbone}_loss"] = loss
+        out["twin_t"] = t
+    save("g13_forward_loss", **out)
+
+
+ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss}
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    g1_schedules()
-    g2_g3_misc()
-    g4_variant_a()
-    g5_dit()
-    g6_g7_loops()
-    g8_chunk_loop()
-    g9_dit_loop()
-    g10_metrics()
-    g11_select_modes()
+    for name in (sys.argv[1:] or list(ALL)):          # no argument: every fixture; otherwise the named ones (g12 g13 ...)
+        ALL[name]()

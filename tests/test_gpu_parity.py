@@ -636,10 +636,10 @@ def test_errors(dev):
         Engine(variant=7, precision=0, d_model=32, n_head=8, n_layers=1, horizon=1, in_dim=4, out_dim=4)
     with pytest.raises(_lib.AdxError, match="device memory"):
         _lib.ptr(torch.zeros(3))
-    w = refiner.DiffusionWrapper(make_a(10), timesteps=10).eval()
-    w.train()
-    with pytest.raises(NotImplementedError):
-        w({}, torch.zeros(1, 10, 4))
+    tr = refiner.TrajectoryRefiner(refiner.refiner_config(frame_stack=10, diffusion_timesteps=10)).to(dev).eval()
+    z4 = torch.zeros(1, 10, 4, device=dev)
+    with pytest.raises(RuntimeError, match="train"):           # forward() is the loss; sampling is generate()
+        tr(z4, z4, z4, torch.zeros(1, 788, 256, device=dev))
     # keeping the map caches needs a previous sampling call at the same batch size
     from autodiffusion_amd import explicit, synth
     td = explicit.TrajDiffusion(explicit.explicit_config(frame_stack=10, num_inference_steps=2)).to(dev).eval()
@@ -703,3 +703,349 @@ def test_trajectory_metrics_kernel(dev, S, C):
     b = sampling.evaluation_metrics(pred.double().numpy(), label.double().numpy())
     for k in b:
         assert abs(a[k] - b[k]) < 2e-5 * max(1.0, abs(b[k])), (k, a[k], b[k])
+
+
+# ------------------------------------------------------------------ the benchmark configurations at their own sizes (G12)
+def _da_reference_init(fs, N, prec, dev, n_sample=None, obj="pred_noise", sched="cosine", residual=False, init="reference"):
+    """DiffusionAugmentation whose refiner follows the recipe the G12 / G13 fixtures were recorded with."""
+    from autodiffusion_amd import refiner, synth
+    cfg = refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective=obj, beta_schedule=sched, precision=prec,
+                                 sampling_timesteps=n_sample, residual=residual)
+    da = refiner.DiffusionAugmentation(cfg)
+    (synth.reference_init_ if init == "reference" else synth.fill_module_)(da.diffusion, WSEED)
+    with torch.no_grad():
+        da.init_x.copy_(synth.seeded_param("init_x", (fs, 4), WSEED))
+    return da.to(dev).eval()
+
+
+def test_config_c1_ddpm_100_steps(dev, golden):
+    """BASELINE configs[0] on the HIP path: frame_stack 10, 8 chunks x 100 ancestral DDPM steps (cosine, pred_noise), B = 2
+    against the trajectory recorded from the reference; fp32 within the per-step gate, split-bf16 within the ADE gate; and
+    B = 16 (the configured batch) bit-identical to itself and to its own rows run alone."""
+    from autodiffusion_amd import metrics, synth
+    g = golden("g12_configs")
+    fs, N = 10, 100
+    ref = T(g["c1_fs10_ddpm100_traj"])
+    for prec in ("fp32", "bf16x3"):
+        da = _da_reference_init(fs, N, prec, dev)
+        maps, prior = synth.maps_info(16, ISEED).to(dev), synth.trajectory_prior(16, ISEED).to(dev)
+        noise = synth.noise(16, (8, N), (fs, 4), NSEED).to(dev)
+        out2 = da.generate(trajectory_prior=prior[:2].contiguous(), maps_info=maps[:2].contiguous(), noise=noise[:, :, :2].contiguous())["traj_logits"]
+        if prec == "fp32":
+            e = rel_err(out2.cpu(), ref)
+            print(f"C1 fp32: rel err {e:.2e}")
+            assert e < GATE
+        ade = float(metrics.ade_fde(out2.cpu(), ref)["ade8"].max())
+        print(f"C1 {prec}: ADE vs reference {ade:.2e} m")
+        assert ade < 1e-2
+        out16 = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].clone()
+        assert torch.equal(out16[:2], out2)
+        assert torch.equal(out16, da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"])
+
+
+def test_config_c3_whole_trajectory_ddim(dev, golden):
+    """BASELINE configs[2]: frame_stack 80 (949 conditioning tokens, 81-row multi-tile tail), in-repo DDIM 10 of 100, eta 0.
+    B = 2 per-step trace and result against the reference recording (fp32 gate); B = 512 -- one GPU's share of the 4096 --
+    in split-bf16: bit-identical re-run, rows independent of their batch, first rows within the ADE gate of the recording."""
+    from autodiffusion_amd import metrics, synth
+    g = golden("g12_configs")
+    fs, N, ns = 80, 100, 10
+    da = _da_reference_init(fs, N, "fp32", dev, ns)
+    w = da.diffusion.diffusion
+    assert w.is_ddim_sampling
+    maps, prior = synth.maps_info(2, ISEED).to(dev), synth.trajectory_prior(2, ISEED).to(dev)
+    noise = synth.noise(2, (1, ns), (fs, 4), NSEED).to(dev)
+    cond = dict(maps_info=maps, transition_info=da.init_x.detach()[None].expand(2, fs, 4).contiguous(), trajectory_prior=prior)
+    res, tx, to = w.sample(cond, torch.zeros(2, fs, 4), noise=noise[0, :1].contiguous(), trace=True)      # eta 0 reads the first draw only
+    for i in range(ns):
+        assert rel_err(tx[i].cpu(), g["c3_fs80_ddim10of100_x"][i]) < GATE, i
+        assert rel_err(to[i].cpu(), g["c3_fs80_ddim10of100_model_out"][i]) < GATE, i
+    assert rel_err(res.cpu(), g["c3_fs80_ddim10of100_traj"]) < GATE
+    out = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise[:, :1].contiguous())["traj_logits"]
+    assert rel_err(out.cpu(), g["c3_fs80_ddim10of100_traj"]) < GATE
+    B = 512
+    db = _da_reference_init(fs, N, "bf16x3", dev, ns)
+    maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED).to(dev)
+    noise = synth.noise(B, (1, 1), (fs, 4), NSEED).to(dev)
+    full = db.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].clone()
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, db.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"])
+    for lo in (0, B - 3):
+        part = db.generate(trajectory_prior=prior[lo:lo + 3].contiguous(), maps_info=maps[lo:lo + 3].contiguous(),
+                           noise=noise[:, :, lo:lo + 3].contiguous())["traj_logits"]
+        assert torch.equal(full[lo:lo + 3], part), f"rows {lo}..{lo + 2} depend on the batch they run in"
+    ade = float(metrics.ade_fde(full[:2].cpu(), T(g["c3_fs80_ddim10of100_traj"]))["ade8"].max())
+    print(f"C3 bf16x3 B=512: ADE of rows 0-1 vs reference {ade:.2e} m")
+    assert ade < 1e-2
+
+
+def test_explicit_whole_trajectory(dev):
+    """ExplicitDiT as explicitDiT_whole.yaml configures it: frame_stack 80 -> ONE token of 320 channels (791 conditioning
+    tokens), 10 diffusers-style DDIM steps of 100.  Against the oracle's restatement (parity unpinned: the reference cannot
+    run this variant and its scheduler is a third-party package)."""
+    from autodiffusion_amd import explicit, synth
+    from oracle import nets, sampling, schedules as osched
+    cfg = explicit.explicit_config(frame_stack=80, num_train_timesteps=100, num_inference_steps=10, data_mean=(50.0, 5.0, 0.0, 0.0),
+                                   data_std=(100.0, 10.0, 1.0, 1.0))
+    m = explicit.ExplicitDiT(cfg)
+    synth.fill_module_(m, WSEED)
+    m = m.to(dev).eval()
+    B = 3
+    maps, prior = synth.maps_info(B, ISEED), synth.trajectory_prior(B, ISEED)
+    noise = synth.noise(B, (1, 1), (1, 320), NSEED)
+    out = m.generate(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), noise=noise.to(dev))["traj_logits"].cpu()
+    assert out.shape == (B, 80, 4)
+    sd = {k[len("diffusion.diffusion."):]: v.detach().float().cpu() for k, v in m.state_dict().items() if k.startswith("diffusion.diffusion.")}
+    ac = np.cumprod(1.0 - osched.squaredcos_cap_v2(100).astype(np.float64))
+
+    def denoise(x, t, tran, pri):
+        return nets.variant_a_forward(sd, x, torch.full((x.shape[0],), int(t), dtype=torch.long), maps, tran, pri)
+    ref = sampling.explicit_generate(denoise, ac, 10, prior, m.init_x.detach().cpu(), noise, 80, cfg.data_mean, cfg.data_std, "ddim")
+    e = rel_err(out, ref)
+    print(f"ExplicitDiT fs=80: rel err {e:.2e}")
+    assert e < GATE
+
+
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_config_c4_sixteen_samples(dev, golden, backbone):
+    """BASELINE configs[3]: d=256 L=4 h=8 decoder, mc_num = 16 samples per scenario, 10 DDPM steps (cosine).  fp32 against the
+    reference recording of the 16 sample rows; split-bf16 within the ADE gate of it; through DiffusionDecoder.generate the
+    same samples come back as (B, 16, 80, 4) and reduce to k modes."""
+    from autodiffusion_amd import dit, metrics, synth
+    g = golden("g12_configs")
+    ref = T(g[f"c4_{backbone}_mc16"])
+    state = synth.hidden_state(1, 256, ISEED).to(dev)
+    noise = synth.noise(16, (11,), (80, 4), NSEED).to(dev)
+    for prec in ("fp32", "bf16x3"):
+        dec = dit.DiffusionDecoder(dit.dit_config(256, 4, 8, backbone, k=16, mc_num=16, diffusion_timesteps=10, precision=prec))
+        synth.fill_module_(dec, WSEED)
+        dec = dec.to(dev).eval()
+        out = dec.generate(state, noise=noise)
+        assert out.shape == (1, 16, 80, 4)
+        if prec == "fp32":
+            e = rel_err(out[0].cpu(), ref)
+            print(f"C4 {backbone} fp32: rel err {e:.2e}")
+            assert e < GATE
+        else:
+            ade = float(metrics.ade_fde(out[0].cpu(), ref)["ade8"].max())
+            print(f"C4 {backbone} bf16x3: ADE vs reference {ade:.2e} m")
+            assert ade < 1e-2
+            dec.k = 6
+            modes = dec.generate(state, noise=noise)
+            assert modes.shape == (1, 6, 80, 4) and bool(torch.isfinite(modes).all())
+
+
+@pytest.mark.parametrize("backbone,L", [("DiT", 2), ("MM-DiT", 1)])
+def test_config_c5_hidden_1024(dev, golden, backbone, L):
+    """BASELINE configs[4]'s width: hidden 1024, 16 heads (head width 64, connect_dim 1600, n_inner 4096).  One denoiser call,
+    B = 2 against the reference recording in fp32 (1e-3 gate) and split-bf16; then B = 192 (15360 token rows: the dispatch
+    sends the block GEMMs to the staged LDS-DMA kernel) whose first rows must agree with the B = 2 call -- a row's result
+    does not depend on the kernel its batch size selects beyond the operand precision."""
+    from autodiffusion_amd import dit, synth
+    g = golden("g12_configs")
+    ref = T(g[f"c5_{backbone}_d1024_out"])
+    x, state, t = synth.noise(192, (), (80, 4), NSEED), synth.hidden_state(192, 1024, ISEED), T(g["c5_t"])
+    for prec, tol in (("fp32", GATE), ("bf16x3", GATE)):
+        m = dit.Transformer_TrajDiffusionModel(dit.dit_config(1024, L, 16, backbone, precision=prec))
+        assert m.connect_dim == 1600
+        synth.fill_module_(m, WSEED)
+        m = m.to(dev).eval()
+        out = m(x[:2].to(dev), t.to(dev), state[:2].to(dev)).cpu()
+        e = rel_err(out, ref)
+        print(f"C5 {backbone} {prec}: rel err {e:.2e}")
+        assert e < tol
+        if prec == "bf16x3" and backbone == "DiT":
+            tt = torch.cat([t, torch.arange(190) % 200]).to(dev)
+            big = m(x.to(dev), tt, state.to(dev)).cpu()
+            e2 = rel_err(big[:2], ref)
+            print(f"C5 {backbone} {prec} B=192: rel err of rows 0-1 {e2:.2e}")
+            assert e2 < tol
+        del m
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_dit_bf16x3_final_ade(dev, backbone):
+    """The mode every DiT number is quoted in, gated: d=256 L=4 h=8, 10 stochastic DDPM steps, B = 8, split-bf16 engine against
+    the fp32 CPU oracle on the same noise -- final trajectories within 1e-2 m ADE.  Weights N(0, 0.02) as the benchmark
+    initialises them (the reference zero-initialises adaLN, which would idle the blocks)."""
+    from autodiffusion_amd import dit, metrics, synth
+    from oracle import nets, sampling, schedules as osched
+    B, N = 8, 10
+    dec = dit.DiffusionDecoder(dit.dit_config(256, 4, 8, backbone, diffusion_timesteps=N, precision="bf16x3"))
+    torch.manual_seed(11)
+    with torch.no_grad():
+        for p in dec.parameters():
+            p.normal_(0.0, 0.02)
+    sd = {k[len("model.model."):]: v.detach().float() for k, v in dec.state_dict().items() if k.startswith("model.model.")}
+    dec = dec.to(dev).eval()
+    state = synth.hidden_state(B, 256, ISEED)
+    noise = synth.noise(B, (N + 1,), (80, 4), NSEED)
+    out = dec.model(state.to(dev), batch_size=B, determin=False, noise=noise.to(dev)).cpu()
+
+    def fn(x, t):
+        return nets.dit_forward(sd, x, torch.full((x.shape[0],), int(t), dtype=torch.long), state, 8, backbone)
+    ref, _ = sampling.twin_sample(fn, osched.buffers_from_betas(osched.twin_betas("cosine", N), f32=True), (B, 80, 4), noise, determin=False)
+    ade = float(metrics.ade_fde(out, ref)["ade8"].max())
+    print(f"{backbone} bf16x3: ADE vs fp32 oracle {ade:.2e} m")
+    assert ade < 1e-2
+
+
+# ------------------------------------------------------------------ evaluation-time loss (G13)
+@pytest.mark.parametrize("tag,fs,N,obj,sched,residual", [("fs10_eps", 10, 100, "pred_noise", "cosine", False),
+                                                         ("fs10_x0_res", 10, 10, "pred_x0", "sigmoid", True),
+                                                         ("fs80_v", 80, 50, "pred_v", "cosine", False)])
+def test_forward_loss(dev, golden, tag, fs, N, obj, sched, residual):
+    """DiffusionAugmentation.forward -- what the HF-Trainer evaluation entry calls before generate() -- with the timesteps and
+    noise of the recording: per-chunk losses and their mean against the reference, the record's fields as the trainer reads them."""
+    from autodiffusion_amd import synth
+    g = golden("g13_forward_loss")
+    da = _da_reference_init(fs, N, "fp32", dev, obj=obj, sched=sched, residual=residual, init="seeded")
+    maps, prior = synth.maps_info(2, ISEED).to(dev), synth.trajectory_prior(2, ISEED).to(dev)
+    noise = synth.noise(2, (80 // fs,), (fs, 4), NSEED + 2).to(dev)
+    label = T(g["label"]).to(dev)
+    out = da(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=T(g[f"{tag}_t"]).to(dev), noise=noise)
+    np.testing.assert_allclose(out.loss_items.cpu().numpy(), g[f"{tag}_loss_items"], rtol=1e-3)
+    np.testing.assert_allclose(float(out.loss), float(g[f"{tag}_loss"]), rtol=1e-3)
+    assert out["logits"].shape == (2, 80, 4) and not out.logits.any() and out.pred_dict["traj_logits"] is out.logits
+    assert set(out.keys()) == {"loss", "logits", "trajectory_label", "loss_items", "pred_dict"}
+    # without supplied draws the loss is a fresh sample: finite, and generate() still works afterwards (eval-entry order)
+    assert bool(torch.isfinite(da(trajectory_prior=prior, maps_info=maps, trajectory_label=label).loss))
+    assert da.generate(trajectory_prior=prior, maps_info=maps)["traj_logits"].shape == (2, 80, 4)
+
+
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_twin_forward_loss(dev, golden, backbone):
+    from autodiffusion_amd import dit, synth
+    g = golden("g13_forward_loss")
+    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, backbone, diffusion_timesteps=10))
+    synth.fill_module_(dec, WSEED)
+    dec = dec.to(dev).train()
+    loss, logits = dec(T(g["label"]).to(dev), synth.hidden_state(2, 64, ISEED).to(dev), t=T(g["twin_t"]).to(dev),
+                       noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
+    np.testing.assert_allclose(float(loss), float(g[f"twin_{backbone}_loss"]), rtol=1e-3)
+    assert logits.shape == (2, 80, 4) and not logits.any()
+
+
+def test_op_q_sample_weighted_mse(dev):
+    from autodiffusion_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x0, nz, out = (torch.randn(37, 10, 4, generator=g) for _ in range(3))
+    t = torch.randint(0, 50, (37,), generator=g)
+    sa, s1, w = torch.rand(50, generator=g), torch.rand(50, generator=g), torch.rand(50, generator=g) * 3
+    xt, v = ops.q_sample(x0.to(dev), nz.to(dev), t.to(dev), sa.to(dev), s1.to(dev), want_v=True)
+    a, b = sa[t].reshape(-1, 1, 1), s1[t].reshape(-1, 1, 1)
+    assert rel_err(xt.cpu(), a * x0 + b * nz) < 1e-6 and rel_err(v.cpu(), a * nz - b * x0) < 1e-6
+    rows, mean = ops.weighted_mse(out.to(dev), nz.to(dev), t.to(dev), w.to(dev))
+    ref = ((out - nz) ** 2).reshape(37, -1).mean(1) * w[t]
+    assert rel_err(rows.cpu(), ref) < 1e-5 and abs(float(mean) - float(ref.mean())) < 1e-5 * float(ref.mean())
+
+
+# ------------------------------------------------------------------ engine state: reloaded weights, fresh tensors, device noise
+def test_reload_weights_through_the_raw_abi(dev):
+    """set_tensor + finalize on an engine that already has a schedule: every weight-derived table (time-token tables, the packed
+    images of the fused row and tail kernels) must follow the new weights without another set_schedule."""
+    from autodiffusion_amd import _lib, schedules, synth
+    from autodiffusion_amd.engine import Engine
+    fs, N, B = 10, 4, 3
+    dims = dict(variant=_lib.VARIANT_A, precision=0, elide=3, d_model=32, n_head=8, n_enc_layers=2, n_layers=4, horizon=fs, in_dim=4,
+                out_dim=4, n_prior_tokens=fs, prior_dim=4, n_maps_token=788, maps_dim=256, map_cond=1)
+    rows = schedules.ddpm_rows(schedules.diffusion_buffers(schedules.make_betas("cosine", N)), "pred_noise")
+    models = []
+    for seed in (WSEED, WSEED + 1):
+        m = make_a(fs)
+        synth.fill_module_(m, seed)
+        models.append([(n, p.detach().to(dev)) for n, p in m.named_parameters()])
+    maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED)[:, :fs].contiguous().to(dev)
+    tran = (prior * 0.5).contiguous()
+    noise = synth.noise(B, (N,), (fs, 4), NSEED).to(dev)
+    flags = _lib.FLAG_NORMALIZE
+    eng = Engine(**dims)
+    eng.load(models[0])
+    eng.set_schedule(rows)
+    out_a = eng.sample_a(maps, tran, prior, noise, flags).clone()
+    eng.load(models[1])                                    # set_tensor x N + finalize; NO set_schedule (its row cache is unchanged)
+    out_b = eng.sample_a(maps, tran, prior, noise, flags).clone()
+    fresh = Engine(**dims)
+    fresh.load(models[1])
+    fresh.set_schedule(rows)
+    out_f = fresh.sample_a(maps, tran, prior, noise, flags)
+    assert not torch.equal(out_a, out_b)
+    assert torch.equal(out_b, out_f), "the reloaded engine samples with tables of the old weights"
+    # a reserve() that moves the workspace forgets the map caches: KEEP_MAPS must be refused, not served from garbage
+    eng.reserve(64)
+    with pytest.raises(_lib.AdxError, match="KEEP_MAPS"):
+        eng.sample_a(maps, tran, prior, noise, flags | _lib.FLAG_KEEP_MAPS)
+
+
+def test_fresh_tensor_callers_capture_once(dev):
+    """A caller that hands in new tensors on every call (what the evaluation loop and the simulator do) must not pay a graph
+    capture per call: the second distinct pointer set switches the shape to the engine's staging buffers, later calls replay."""
+    from autodiffusion_amd import dit, synth
+    da = _make_da(10, 4, "fp32", "seeded", dev)
+    B = 3
+    maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED).to(dev)
+    noise = synth.noise(B, (8, 4), (10, 4), NSEED).to(dev)
+    eng = da.diffusion.diffusion.model.engine()
+    outs, counts = [], []
+    for _ in range(5):
+        outs.append(da.generate(trajectory_prior=prior.clone(), maps_info=maps.clone(), noise=noise.clone())["traj_logits"])
+        counts.append(eng.capture_count())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert counts[0] == 1 and counts[1] == 2 and counts[-1] == 2, counts
+    # a caller with stable buffers is never staged: one capture, ever
+    db = _make_da(10, 4, "fp32", "seeded", dev)
+    for _ in range(3):
+        db.generate(trajectory_prior=prior, maps_info=maps, noise=noise)
+    assert db.diffusion.diffusion.model.engine().capture_count() == 1
+    # noise=None (drawn on the device): fresh conditioning tensors, still at most two captures
+    dc = _make_da(10, 4, "fp32", "seeded", dev)
+    for _ in range(4):
+        dc.generate(trajectory_prior=prior.clone(), maps_info=maps.clone())
+    assert dc.diffusion.diffusion.model.engine().capture_count() == 2
+    # the DiT sampler follows the same policy
+    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "DiT", diffusion_timesteps=4))
+    synth.fill_module_(dec, WSEED)
+    dec = dec.to(dev).eval()
+    st = synth.hidden_state(2, 64, ISEED).to(dev)
+    nz = synth.noise(2, (5,), (80, 4), NSEED).to(dev)
+    res = [dec.model(st.clone(), batch_size=2, determin=False, noise=nz.clone()) for _ in range(4)]
+    assert all(torch.equal(res[0], r) for r in res[1:])
+    assert dec.model.model.engine().capture_count() == 2
+
+
+def test_device_noise(dev):
+    """noise=None: the generator kernel against its NumPy restatement, its statistics, and what sampling does with it --
+    repeatable per seed, different across seeds, equal to passing the same numbers in as a tensor, and shard-invariant
+    (rows 2..5 of a 6-row run == a 4-row run with row0 = 2)."""
+    from autodiffusion_amd import ops, synth
+    from oracle import sampling
+    z = ops.randn(3, 50, 40, seed=2024, row0=7, device=dev).cpu().numpy()
+    np.testing.assert_allclose(z, sampling.philox_randn(3, 50, 40, 2024, 7), atol=2e-6)
+    odd = ops.randn(2, 5, 7, seed=3, device=dev).cpu().numpy()                       # row length not a multiple of four
+    np.testing.assert_allclose(odd, sampling.philox_randn(2, 5, 7, 3), atol=2e-6)
+    big = ops.randn(4, 4096, 40, seed=1, device=dev)
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3
+    assert abs(float((big ** 4).mean()) - 3.0) < 0.1
+    fs, N, B = 10, 4, 6
+    da = _make_da(fs, N, "fp32", "seeded", dev)                                      # DDPM: 1 + 3 draws per chunk
+    maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED).to(dev)
+    a = da.generate(trajectory_prior=prior, maps_info=maps, seed=5)["traj_logits"].clone()
+    b = da.generate(trajectory_prior=prior, maps_info=maps, seed=5)["traj_logits"].clone()
+    c = da.generate(trajectory_prior=prior, maps_info=maps, seed=6)["traj_logits"].clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    explicit = ops.randn(8 * 4, B, fs * 4, seed=5, device=dev).reshape(8, 4, B, fs, 4)
+    assert torch.equal(a, da.generate(trajectory_prior=prior, maps_info=maps, noise=explicit)["traj_logits"])
+    part = da.generate(trajectory_prior=prior[2:].contiguous(), maps_info=maps[2:].contiguous(), seed=5, row0=2)["traj_logits"]
+    assert torch.equal(a[2:], part)
+    torch.manual_seed(3)
+    d1 = da.generate(trajectory_prior=prior, maps_info=maps)["traj_logits"].clone()
+    torch.manual_seed(3)
+    assert torch.equal(d1, da.generate(trajectory_prior=prior, maps_info=maps)["traj_logits"])
+    # deterministic DDIM reads one draw per chunk, and only that one is generated
+    dd = _make_da(fs, 10, "fp32", "seeded", dev, n_sample=5)
+    from autodiffusion_amd import schedules
+    assert schedules.n_noise_draws(dd.diffusion.diffusion.schedule_rows()) == 0
+    e1 = dd.generate(trajectory_prior=prior, maps_info=maps, seed=9)["traj_logits"].clone()
+    init = ops.randn(8, B, fs * 4, seed=9, device=dev).reshape(8, 1, B, fs, 4)
+    assert torch.equal(e1, dd.generate(trajectory_prior=prior, maps_info=maps, noise=init)["traj_logits"])

@@ -316,3 +316,119 @@ def test_select_modes_golden(golden, tag, k):
     # farthest-point sampling starts at sample 0 and never repeats a point while distinct ones remain
     idx = modes.farthest_point_indices(traj[:, :, -1, :], k)
     assert (idx[:, 0] == 0).all() and all(len(set(r.tolist())) == k for r in idx)
+
+
+# ------------------------------------------------------------------ G12: the benchmark configurations at their own sizes
+def reference_init_refiner_sd(fs, N, obj="pred_noise", sched="cosine", residual=False, init="reference"):
+    """State dict of the denoiser inside a TrajectoryRefiner whose parameters follow the recipe the G12 / G13 fixtures were
+    recorded with ("reference": N(0, 0.02) matrices, zero biases, unit gains; "seeded": every tensor random)."""
+    from autodiffusion_amd import refiner
+    cfg = refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective=obj, beta_schedule=sched, residual=residual)
+    tr = refiner.TrajectoryRefiner(cfg)
+    (synth.reference_init_ if init == "reference" else synth.fill_module_)(tr, WSEED)
+    return {k[len("diffusion.model."):]: v.detach().float() for k, v in tr.state_dict().items() if k.startswith("diffusion.model.")}
+
+
+def _cond_denoiser(sd, maps):
+    def fn(x, t, tra_n, pri_n):
+        tt = t if torch.is_tensor(t) else torch.full((x.shape[0],), int(t), dtype=torch.long)
+        return nets.variant_a_forward(sd, x, tt, maps, tra_n, pri_n)
+    return fn
+
+
+def test_config_c3_whole_trajectory_ddim(golden):
+    """frame_stack 80, in-repo DDIM 10 of 100 (eta 0): per-step inputs / outputs and the final (mostly clamped) sample."""
+    g = golden("g12_configs")
+    fs, N, ns = 80, 100, 10
+    maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
+    fn = _cond_denoiser(reference_init_refiner_sd(fs, N), maps)
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    noise = synth.noise(2, (1, ns), (fs, 4), NSEED)
+    trace = {}
+    res = sampling.refiner_sample(fn, schedules.buffers("cosine", N, "pred_noise"), "pred_noise", init_x[None].expand(2, fs, 4), prior,
+                                  noise[0], n_sample=ns, trace=trace)
+    for i in range(ns):
+        assert rel_err(trace["x"][i], g["c3_fs80_ddim10of100_x"][i]) < 1e-4, i
+        assert rel_err(trace["model_out"][i], g["c3_fs80_ddim10of100_model_out"][i]) < 1e-4, i
+    assert rel_err(res, g["c3_fs80_ddim10of100_traj"]) < 1e-4
+
+
+def test_config_c1_ddpm100_first_chunks(golden):
+    """frame_stack 10, 100-step DDPM: the first two of the eight chunks (200 denoiser calls) against the recorded trajectory."""
+    g = golden("g12_configs")
+    fs, N = 10, 100
+    maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
+    fn = _cond_denoiser(reference_init_refiner_sd(fs, N), maps)
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    noise = synth.noise(2, (8, N), (fs, 4), NSEED)
+    out = sampling.refiner_generate(fn, schedules.buffers("cosine", N, "pred_noise"), "pred_noise", maps, prior[:, :2 * fs], init_x,
+                                    noise[:2], fs)
+    assert rel_err(out, g["c1_fs10_ddpm100_traj"][:, :2 * fs]) < 2e-4
+
+
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_config_c4_sixteen_samples(golden, backbone):
+    """d=256 L=4 h=8 decoder, 16 stochastic samples of one scenario, 10 DDPM steps."""
+    g = golden("g12_configs")
+    sd = dit_sd(256, 4, 8, backbone, prefix="model.model.")
+    state = torch.repeat_interleave(synth.hidden_state(1, 256, ISEED), 16, dim=0)
+
+    def fn(x, t):
+        return nets.dit_forward(sd, x, torch.full((x.shape[0],), int(t), dtype=torch.long), state, 8, backbone)
+    b = schedules.buffers_from_betas(schedules.twin_betas("cosine", 10), f32=True)
+    sto, _ = sampling.twin_sample(fn, b, (16, 80, 4), synth.noise(16, (11,), (80, 4), NSEED), determin=False)
+    assert rel_err(sto, g[f"c4_{backbone}_mc16"]) < 5e-4
+
+
+@pytest.mark.parametrize("backbone,L", [("DiT", 2), ("MM-DiT", 1)])
+def test_config_c5_hidden_1024(golden, backbone, L):
+    """One denoiser call at hidden 1024, 16 heads: the connect_dim = 1600 special case of the state encoder, head width 64."""
+    g = golden("g12_configs")
+    sd = dit_sd(1024, L, 16, backbone)
+    assert sd["state_encoder.0.fc.weight"].shape == (1600, 4096 + 1024)
+    out = nets.dit_forward(sd, synth.noise(2, (), (80, 4), NSEED), T(g["c5_t"]), synth.hidden_state(2, 1024, ISEED), 16, backbone)
+    assert rel_err(out, g[f"c5_{backbone}_d1024_out"]) < 5e-5
+
+
+# ------------------------------------------------------------------ G13: evaluation-time loss
+@pytest.mark.parametrize("tag,fs,N,obj,sched,residual", [("fs10_eps", 10, 100, "pred_noise", "cosine", False),
+                                                         ("fs10_x0_res", 10, 10, "pred_x0", "sigmoid", True),
+                                                         ("fs80_v", 80, 50, "pred_v", "cosine", False)])
+def test_forward_loss(golden, tag, fs, N, obj, sched, residual):
+    g = golden("g13_forward_loss")
+    maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
+    fn = _cond_denoiser(reference_init_refiner_sd(fs, N, obj, sched, residual, init="seeded"), maps)
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    noise = synth.noise(2, (80 // fs,), (fs, 4), NSEED + 2)
+    loss, items = sampling.refiner_forward(fn, schedules.buffers(sched, N, obj), obj, prior, T(g["label"]), init_x, T(g[f"{tag}_t"]), noise,
+                                           fs, residual=residual)
+    np.testing.assert_allclose(items.numpy(), g[f"{tag}_loss_items"], rtol=2e-4)
+    np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=2e-4)
+
+
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
+def test_twin_forward_loss(golden, backbone):
+    g = golden("g13_forward_loss")
+    sd = dit_sd(64, 2, 4, backbone, prefix="model.model.")
+    state = synth.hidden_state(2, 64, ISEED)
+    b = schedules.buffers_from_betas(schedules.twin_betas("cosine", 10), f32=True)
+    loss = sampling.twin_loss(lambda x, t: nets.dit_forward(sd, x, t, state, 4, backbone), b, T(g["label"]), T(g["twin_t"]),
+                              synth.noise(2, (), (80, 4), NSEED + 2))
+    np.testing.assert_allclose(float(loss.sum()), float(g[f"twin_{backbone}_loss"]), rtol=2e-4)
+
+
+def test_philox_generator_statistics():
+    """The counter-based generator's restatement: known first words of Philox4x32-10 (the published test vector for an all-zero
+    counter and key), then mean / variance / independence of rows, leading indices and seeds."""
+    kat = [([0, 0, 0, 0], (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ([0xffffffff] * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:             # Random123's known-answer vectors for philox4x32, 10 rounds
+        assert tuple(int(v) for v in sampling.philox4x32_10(ctr, *key)) == want
+    z = sampling.philox_randn(3, 64, 400, seed=99, row0=5)
+    assert z.shape == (3, 64, 400) and z.dtype == np.float32
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    assert abs(np.corrcoef(z[0, 0], z[0, 1])[0, 1]) < 0.2 and abs(np.corrcoef(z[0, 0], z[1, 0])[0, 1]) < 0.2
+    # a shard that starts at global row 20 draws what rows 20.. of the full batch draw
+    np.testing.assert_array_equal(sampling.philox_randn(3, 10, 400, seed=99, row0=25), z[:, 20:30])
+    assert not np.array_equal(sampling.philox_randn(1, 4, 8, seed=1), sampling.philox_randn(1, 4, 8, seed=2))
