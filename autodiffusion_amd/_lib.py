@@ -28,6 +28,7 @@ EXPORTS = [
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
     "adx_generate_a", "adx_sample_dit", "adx_debug_stage_a", "adx_op_select_modes", "adx_op_trajectory_metrics", "adx_engine_profile", "adx_engine_profile_read",
     "adx_engine_set_noise_seed", "adx_op_randn", "adx_engine_capture_count", "adx_op_q_sample", "adx_op_weighted_mse",
+    "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes",
 ]
 
 
@@ -91,6 +92,8 @@ def load() -> C.CDLL:
         "adx_engine_set_noise_seed": ([p, C.c_uint64, i64], i),
         "adx_op_randn": ([p, i, i, i, C.c_uint64, i64, p, p], i),
         "adx_engine_capture_count": ([p], i64),
+        "adx_op_linear_noalloc": ([p, p, p, p, i, i, i, i, i, p], i),
+        "adx_noalloc_scratch_bytes": ([], C.c_size_t),
         "adx_op_q_sample": ([p, p, p, p, p, p, p, i, i, p], i),
         "adx_op_weighted_mse": ([p, p, p, p, p, p, i, i, p], i),
     }

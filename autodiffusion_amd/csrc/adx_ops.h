@@ -39,6 +39,7 @@ struct LinearArgs {
     // at least linear_stage_bytes(M, Wblk ? 0 : N, K, prec) bytes; enables the LDS-DMA form of the large-tile kernel
     void* xstage = nullptr; size_t xstage_bytes = 0;
     const void* Wblk = nullptr; const void* Wblk_lo = nullptr;      // W already in the K-blocked layout [K/16][N][16]
+    bool force_staged = false;          // take the staged (LDS-DMA) kernel whatever the shape, when xstage is large enough
 };
 size_t linear_stage_bytes(int M, int N, int K, int prec);
 hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream);   // [N][K] bf16 -> [K/16][N][16]

@@ -1056,13 +1056,14 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     // N=1536 523 against 591; single-pass bf16 M=327680 N=1024 404 against 755.  Slower at N=256 (241 against 228).
     const char* rows_env = getenv("ADX_GEMM_ROWS");             // read per call (tests switch it): 0 never, 1 whenever legal
     const int rows_mode = rows_env ? atoi(rows_env) : -1;
-    if (force_wm == 0 && rows_mode != 0 && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N && linear_vec_ok(a) &&
+    if (force_wm == 0 && rows_mode != 0 && !a.force_staged && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N && linear_vec_ok(a) &&
         ((a.M >= 160 * 1024 && a.N >= 512) || rows_mode == 1))
         return a.prec == PREC_BF16X3 ? launch_rows<true>(a, stream) : launch_rows<false>(a, stream);
     static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();
     const int64_t tiles_sq = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    static const bool glds_any = [] { const char* e = getenv("ADX_GEMM_DMA_ANY"); return e && e[0] == '1'; }();     // measurement switch
-    if (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any) && a.xstage &&
+    const char* any_env = getenv("ADX_GEMM_DMA_ANY");             // read per call (tests switch it): the staged kernel for any shape
+    const bool glds_any = any_env && any_env[0] == '1';
+    if (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any || a.force_staged) && a.xstage &&
         a.xstage_bytes >= linear_stage_bytes(a.M, a.Wblk ? 0 : a.N, a.K, a.prec) && (reinterpret_cast<uintptr_t>(a.xstage) & 15) == 0 &&
         (int64_t)a.M * a.K < ((int64_t)1 << 31) && (int64_t)a.N * a.K < ((int64_t)1 << 31))
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);

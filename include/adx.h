@@ -69,6 +69,15 @@ int adx_op_linear(const float* x, const void* w, const float* bias, float* y, in
 int adx_op_linear_staged(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
                          int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t adx_linear_stage_bytes(int M, int N, int K, int prec);
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under hipGraph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): adx_op_linear_staged with the staging workspace taken from a fixed device array inside
+ * the library (adx_noalloc_scratch_bytes() = 64 MiB per GPU, held until the process ends) -- the call allocates nothing.  Always
+ * runs the staged kernel, so it needs M >= 256, N >= 64, K a multiple of 64, a bf16 precision, and
+ * adx_linear_stage_bytes(M, N, K, prec) <= adx_noalloc_scratch_bytes(); anything else is ADX_EINVAL.  Results equal
+ * adx_op_linear_staged's bit for bit.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU race. */
+int adx_op_linear_noalloc(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act, int prec,
+                          void* stream);
+size_t adx_noalloc_scratch_bytes(void);
 int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 
 /* select_k_from_mc (models/utils.py:120-132 -> utils/modify_traj_utils.py: farthest_point_sample_PointCloud :8-30,
