@@ -235,6 +235,15 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
     }
 }
 
+// The epilogue of this call can use 16-byte accesses for every operand.
+__device__ __forceinline__ bool linear_vec_ok_dev(const LinearArgs& a) {
+    return (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (a.N & 3) == 0 && (a.ldy & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.Y) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) &&
+           (!a.pos || ((a.ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(a.pos) & 15) == 0)) &&
+           (!a.gate || ((a.ldg & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gate) & 15) == 0)) &&
+           (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+}
+
 // The bias of the two 32-column patches of a wave's 64-column sub-tile, as this lane will use them in the vector epilogue.
 __device__ __forceinline__ void load_patch_bias(const LinearArgs& a, int n_base, int lane, bool vec, float4 (&bv)[2]) {
 #pragma unroll
@@ -749,6 +758,203 @@ __global__ __launch_bounds__(512, 1) void linear_glds_kernel(const LinearArgs a,
     if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
 }
 
+// ============================================================================================================
+// Two-workgroups-per-CU form of the LDS-DMA kernel: a 256x128 tile per 256-thread workgroup, 4 waves as 2x2, each a 128x64
+// sub-tile (4x2 accumulators, the same per-wave work as above).  A CU holds TWO such workgroups (72 KB of LDS and
+// <= 256 registers each), one wave of each per SIMD, and nothing synchronises them: while one workgroup writes its
+// 128 KB of fp32 results (no MFMAs for thousands of cycles) or waits at its barrier, the other one's main loop has the matrix
+// pipe to itself, so the epilogue, the copy waits and the fragment-read latency of one tile hide under the products of
+// another -- with one workgroup per CU they were serial (the 256x256 kernel spends 20 % of its time in the epilogue).
+// Per K-step (k = 16) and workgroup: ring slot = [A_hi 8 KB][B_hi 4 KB][A_lo 8 KB][B_lo 4 KB] (split) or [A][B] (plain);
+// R = 3 slots of 24 KB or 6 of 12 KB: the copies of R - 1 steps are in flight while one step is multiplied; ONE barrier
+// per step: it publishes step kt + 1 (every wave waited for its own copies) and frees the slot of step kt (every wave
+// holds those fragments in registers).  Copies are issued from inline assembly and ordered by counted waits (see
+// dma16_unordered): the fragment reads of step kt + 1 and the copies of step kt + R run under the MFMAs of step kt.
+// ============================================================================================================
+constexpr int G2_TM = 256, G2_TN = 128;
+constexpr int G2_A_B = G2_TM * GROW_B;            // 8 KB
+constexpr int G2_B_B = G2_TN * GROW_B;            // 4 KB
+
+template <bool X3>
+__device__ __forceinline__ void load_frags2(Frags<X3>& f, const unsigned char* st, int wr, int wc, int fr, int fc) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.bh[j] = *reinterpret_cast<const bf16x8*>(st + G2_A_B + gswz(wc * 64 + j * 32 + fr, fc));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.ah[i] = *reinterpret_cast<const bf16x8*>(st + gswz(wr * 128 + i * 32 + fr, fc));
+    if constexpr (X3) {
+        constexpr int LO = G2_A_B + G2_B_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.bl[j] = *reinterpret_cast<const bf16x8*>(st + LO + G2_A_B + gswz(wc * 64 + j * 32 + fr, fc));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.al[i] = *reinterpret_cast<const bf16x8*>(st + LO + gswz(wr * 128 + i * 32 + fr, fc));
+    }
+}
+
+template <bool X3, int ABL>
+__global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a, const StagedOperands so, int tiles_n, int n_tiles, int pw) {
+    constexpr int STAGE_B = (X3 ? 2 : 1) * (G2_A_B + G2_B_B);                  // 24 KB / 12 KB
+    constexpr int R = X3 ? 3 : 6;                                              // 72 KB
+    constexpr int P = X3 ? 6 : 3;                                              // copy instructions per wave per K-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // R * STAGE_B
+    // workgroup -> tile: XCD x (blockIdx % 8) walks a contiguous range of a PANEL order -- column panels of `pw` tiles, inside a
+    // panel row by row -- so the ~64 workgroups resident on an XCD at one time form a block of about 8 x 8 tiles: per K-step
+    // they fetch 8 row-slabs of X and 8 of W into that XCD's L2 (a 2 x 32 block of the row-major order fetches 2 + 32)
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (lin >= n_tiles) return;
+    const int tiles_m = n_tiles / tiles_n;
+    int tm, tn;
+    if (pw > 0) {
+        const int full = (tiles_n / pw) * pw;                    // columns covered by whole panels
+        const int in_full = tiles_m * full;
+        if (lin < in_full) { const int p = lin / (tiles_m * pw), q = lin % (tiles_m * pw); tm = q / pw; tn = p * pw + q % pw; }
+        else { const int w = tiles_n - full, q = lin - in_full; tm = q / w; tn = full + q % w; }
+    } else if (pw < 0) {                                         // experiment: bands of -pw tile rows, column by column inside a band
+        const int bh = -pw, full = (tiles_m / bh) * bh, in_full = full * tiles_n;
+        if (lin < in_full) { const int p = lin / (bh * tiles_n), q = lin % (bh * tiles_n); tn = q / bh; tm = p * bh + q % bh; }
+        else { const int h = tiles_m - full, q = lin - in_full; tn = q / h; tm = full + q % h; }
+    } else { tm = lin / tiles_n; tn = lin % tiles_n; }
+    const int m0 = tm * G2_TM, n0 = tn * G2_TN;
+    const int M = a.M, N = a.N, K = a.K;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fc = lane >> 5;
+
+    // ---- copy plan: a slab = 32 image rows = 1 KB = one wave-instruction.  Wave w copies slabs w and w + 4 of the A images
+    // and slab w of the B images; the swizzle of the image is applied to the SOURCE element of each lane.
+    const int r = wave * 32 + (lane >> 1);
+    const unsigned half = 8u * (unsigned)((lane & 1) ^ ((r >> 3) & 1));
+    const unsigned xoff0 = (unsigned)min(m0 + r, M - 1) * 16u + half, xoff1 = (unsigned)min(m0 + r + 128, M - 1) * 16u + half;
+    const unsigned woff = (unsigned)min(n0 + r, N - 1) * 16u + half;
+    const unsigned xstep = (unsigned)M * 16u, wstep = (unsigned)N * 16u;
+    const int nk = K / GK;
+    auto issue = [&](int kt, int slot) {             // K-step kt (clamped: steps past the end repeat the last one) -> ring slot
+        unsigned char* st = smem + slot * STAGE_B + wave * 1024;
+        const int kc = min(kt, nk - 1);
+        const unsigned xo = (unsigned)kc * xstep, wo = (unsigned)kc * wstep + woff;
+        dma16_unordered(so.xh + xo + xoff0, st);
+        dma16_unordered(so.xh + xo + xoff1, st + 4096);
+        dma16_unordered(so.wh + wo, st + G2_A_B);
+        if constexpr (X3) {
+            constexpr int LO = G2_A_B + G2_B_B;
+            dma16_unordered(so.xl + xo + xoff0, st + LO);
+            dma16_unordered(so.xl + xo + xoff1, st + LO + 4096);
+            dma16_unordered(so.wl + wo, st + LO + G2_A_B);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+#pragma unroll
+    for (int t = 0; t < R; ++t) issue(t, t);
+    // all but the (R - 1) youngest steps of this wave's copies have landed: step 0
+    if constexpr (X3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags<X3> f0, f1;
+    load_frags2<X3>(f0, smem, wr, wc, fr, fc);
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
+    int slot = 0;                                    // ring slot of step kt
+    auto step = [&](int kt, Frags<X3>& cur, Frags<X3>& nxt) {
+        // this wave's copies of step kt + 1 have landed (the R - 2 younger steps may still fly) ...
+        if constexpr (X3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // ... and so have everybody's; everybody holds step kt in registers, so its slot can be refilled
+        __builtin_amdgcn_s_barrier();
+        const int nslot = slot + 1 == R ? 0 : slot + 1;
+        if constexpr (ABL & 16) {
+            // fine-grained form: the fragment reads of the next step and the copies of step kt + R are spread between the
+            // MFMA groups of this step (one accumulator = one group), so that no burst of LDS reads or copy issues sits in
+            // front of the first MFMA
+            const unsigned char* ns = smem + nslot * STAGE_B;
+            unsigned char* st = smem + slot * STAGE_B + wave * 1024;
+            const int kc = (ABL & 64) ? 0 : min(kt + R, nk - 1);    // measurement aid (64): every copy re-reads K-step 0 (L1 / L2 hits only)
+            const unsigned xo = (unsigned)kc * xstep, wo = (unsigned)kc * wstep + woff;
+            constexpr int LO = G2_A_B + G2_B_B;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int i = g >> 1, j = g & 1;
+                // reads: g 0: bh0, ah0 | 1: bh1, bl0/ah1 | ...   (order: what the next step's first groups need comes first)
+                if constexpr (!(ABL & 1)) {
+                if (g == 0) { nxt.bh[0] = *reinterpret_cast<const bf16x8*>(ns + G2_A_B + gswz(wc * 64 + fr, fc));
+                              nxt.ah[0] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + fr, fc)); }
+                if (g == 1) { nxt.bh[1] = *reinterpret_cast<const bf16x8*>(ns + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
+                              nxt.ah[1] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 32 + fr, fc)); }
+                if (g == 2) { nxt.ah[2] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 64 + fr, fc));
+                              nxt.ah[3] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 96 + fr, fc)); }
+                if constexpr (X3) {
+                    if (g == 3) { nxt.bl[0] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + fr, fc));
+                                  nxt.al[0] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + fr, fc)); }
+                    if (g == 4) { nxt.bl[1] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
+                                  nxt.al[1] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 32 + fr, fc)); }
+                    if (g == 5) nxt.al[2] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 64 + fr, fc));
+                    if (g == 6) nxt.al[3] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 96 + fr, fc));
+                }
+                }
+                if constexpr (!(ABL & 2)) {
+                if (g == 1) dma16_unordered(so.xh + xo + xoff0, st);
+                if (g == 2) dma16_unordered(so.xh + xo + xoff1, st + 4096);
+                if (g == 3) dma16_unordered(so.wh + wo, st + G2_A_B);
+                if constexpr (X3) {
+                    if (g == 4) dma16_unordered(so.xl + xo + xoff0, st + LO);
+                    if (g == 5) dma16_unordered(so.xl + xo + xoff1, st + LO + 4096);
+                    if (g == 6) dma16_unordered(so.wl + wo, st + LO + G2_A_B);
+                }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(ABL & 4)) {
+                if constexpr (X3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl[j], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh[j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            if (!(ABL & 2)) issue(kt + R, slot);
+            if (!(ABL & 1)) load_frags2<X3>(nxt, smem + nslot * STAGE_B, wr, wc, fr, fc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 4)) mfma_frags<X3>(acc, cur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        slot = nslot;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, f0, f1);
+        step(kt + 1, f1, f0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // every wave is done reading, no copy is in flight
+    float* ep = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const bool vec = linear_vec_ok_dev(a);
+    if (ABL & 8) {          // measurement aid: keep the accumulators alive with one store per lane instead of the epilogue
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += acc[t >> 1][t & 1][q];
+        a.Y[(int64_t)min(m0 + wr * 128 + fr, M - 1) * a.ldy + min(n0 + wc * 64 + fc, N - 1)] = sum;
+    }
+    float4 bv[2];
+    load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
+    auto patches = [&](auto extra) {
+#pragma unroll
+        for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
+            const int i = t >> 1, j = t & 1;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
+            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+        }
+    };
+    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
+}
+
 // X (fp32, row map, optional SiLU) -> K-blocked bf16 planes [K/16][M][16]: high halves and, when lo != nullptr,
 // bf16(x - high).  A thread converts 8 consecutive elements; threads run over the rows of one K-step first, so the
 // writes are contiguous.
@@ -783,7 +989,8 @@ __global__ __launch_bounds__(256) void stage_w_kernel(const unsigned short* __re
 template <bool X3>
 static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
     constexpr size_t smem = (X3 ? 4 : 8) * (X3 ? 4 : 2) * (size_t)GIMG_B;      // ring of K-step buffers: 128 KB
-    static const int abl = [] { const char* e = getenv("ADX_GLDS_ABLATE"); return e ? atoi(e) : 0; }();
+    const char* abl_env = getenv("ADX_GLDS_ABLATE");        // read per call
+    const int abl = abl_env ? atoi(abl_env) : 0;
     auto kern = &linear_glds_kernel<X3, 0>;
     switch (abl) {          // measurement aid: bit 0 no LDS reads, bit 1 no copies, bit 2 no MFMAs, bit 3 no epilogue (results are wrong)
         case 1: kern = &linear_glds_kernel<X3, 1>; break;
@@ -813,6 +1020,39 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(stage_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(a.W), a.N, a.K, wh);
         if (X3) hipLaunchKernelGGL(stage_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(a.Wlo), a.N, a.K, wl);
         so.wh = wh; so.wl = wl;
+    }
+    const char* form_env = getenv("ADX_GLDS_FORM");        // read per call: 1 = one 8-wave workgroup per CU (256x256 tiles), 2 = two 4-wave ones (256x128)
+    const int form = form_env ? atoi(form_env) : 2;
+    if (form == 2) {
+        constexpr size_t smem2 = (X3 ? 3 : 6) * (X3 ? 2 : 1) * (size_t)(G2_A_B + G2_B_B);      // 72 KB: two workgroups per CU
+        auto kern2 = &linear_glds2_kernel<X3, 16>;
+        switch (abl) {      // measurement aid, as above (32: the un-interleaved step)
+            case 32: kern2 = &linear_glds2_kernel<X3, 0>; break;
+            case 1: kern2 = &linear_glds2_kernel<X3, 1>; break;
+            case 2: kern2 = &linear_glds2_kernel<X3, 2>; break;
+            case 3: kern2 = &linear_glds2_kernel<X3, 3>; break;
+            case 4: kern2 = &linear_glds2_kernel<X3, 4>; break;
+            case 8: kern2 = &linear_glds2_kernel<X3, 8>; break;
+            case 11: kern2 = &linear_glds2_kernel<X3, 11>; break;
+            case 16: kern2 = &linear_glds2_kernel<X3, 16>; break;
+            case 24: kern2 = &linear_glds2_kernel<X3, 24>; break;
+            case 17: kern2 = &linear_glds2_kernel<X3, 17>; break;
+            case 18: kern2 = &linear_glds2_kernel<X3, 18>; break;
+            case 19: kern2 = &linear_glds2_kernel<X3, 19>; break;
+            case 20: kern2 = &linear_glds2_kernel<X3, 20>; break;
+            case 27: kern2 = &linear_glds2_kernel<X3, 27>; break;
+            case 80: kern2 = &linear_glds2_kernel<X3, 80>; break;
+            default: break;
+        }
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess)
+            return hipErrorInvalidValue;
+        const int tiles_m = (a.M + G2_TM - 1) / G2_TM, tiles_n = (a.N + G2_TN - 1) / G2_TN;
+        const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
+        const int blocks = (int)((n_tiles + 7) / 8) * 8;
+        const char* pw_env = getenv("ADX_GLDS_PANEL");       // tuning knob, read per call: panel width in tiles (0 = row-major order)
+        const int pw = pw_env ? atoi(pw_env) : 8;
+        hipLaunchKernelGGL(kern2, dim3(blocks), dim3(256), smem2, stream, a, so, tiles_n, (int)n_tiles, (pw < tiles_n) ? pw : 0);
+        return hipGetLastError();
     }
     const int tiles_m = (a.M + GT - 1) / GT, tiles_n = (a.N + GT - 1) / GT;
     const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
