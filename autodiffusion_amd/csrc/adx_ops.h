@@ -40,7 +40,19 @@ struct LinearArgs {
     void* xstage = nullptr; size_t xstage_bytes = 0;
     const void* Wblk = nullptr; const void* Wblk_lo = nullptr;      // W already in the K-blocked layout [K/16][N][16]
     bool force_staged = false;          // take the staged (LDS-DMA) kernel whatever the shape, when xstage is large enough
+    // X already as K-blocked bf16 planes [K/16][M][16] (high halves; low halves with PREC_BF16X3), rows in identity order, any
+    // input activation already applied: the staged kernel then runs without its re-layout pass over X, and X itself may be null.
+    // Only legal when linear_planes_ok(M, N, K, prec).
+    const unsigned short* Xh = nullptr; const unsigned short* Xl = nullptr;
+    // Also store the result as K-blocked planes of the NEXT product's operand, [N/16][M][16] (Yl may be null: high halves only);
+    // Y may then be null (planes only).  Large-tile kernels only (linear_big_ok), 16-byte epilogue, no column map.
+    unsigned short* Yh = nullptr; unsigned short* Yl = nullptr;
 };
+// A call with pre-staged X planes (and a pre-blocked or stageable W) takes the staged kernel: bf16 precisions, K a multiple of 32,
+// enough 256 x 128 tiles to fill the chip.
+bool linear_planes_ok(int M, int N, int K, int prec);
+// x[M][K] (row stride ldx, optional SiLU) -> K-blocked planes [K/16][M][16]: hi = bf16(x), lo (nullable) = bf16(x - hi).
+hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream);
 size_t linear_stage_bytes(int M, int N, int K, int prec);
 hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream);   // [N][K] bf16 -> [K/16][N][16]
 hipError_t linear(const LinearArgs& a, hipStream_t stream);        // picks linear_big when linear_big_ok(a)
@@ -58,6 +70,9 @@ struct LayerNormArgs {
     float eps = 1e-5f;
     int rows = 0, d = 0;
     int relu = 0;
+    // also (or, with y == nullptr, only) store the result as K-blocked bf16 planes [d/16][rows][16] for a following product:
+    // ph = bf16(v), pl (nullable) = bf16(v - ph).  d a multiple of 256 (the register-resident kernel), identity row order.
+    unsigned short* ph = nullptr; unsigned short* pl = nullptr;
 };
 hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream);
 

@@ -29,6 +29,8 @@ struct Param {
     float* f32 = nullptr;
     uint16_t* bf16 = nullptr;
     uint16_t* bf16lo = nullptr;   // bf16(w - bf16(w)), for the split-operand GEMM
+    uint16_t* blk = nullptr;      // the same two planes in the K-blocked layout [K/16][N][16] the staged GEMM copies from (built by
+    uint16_t* blk_lo = nullptr;   // finalize() for engines that ask for it), so that no call re-lays the weights
     std::vector<int64_t> shape;
     int64_t numel = 0;
 };
@@ -103,6 +105,7 @@ struct adx_engine {
     virtual int carve_workspace(int max_batch, bool dry_run, size_t* bytes) = 0;
     virtual int build_time_table(hipStream_t s) = 0;   // fills temb_table and every weight-derived table for the current schedule
     virtual void on_workspace_realloc() {}             // caches that live in the workspace are gone
+    virtual bool wants_blocked_weights() const { return false; }   // keep K-blocked copies of the 2-D parameters (staged GEMM operands)
 
     int set_tensor(const char* name, const float* data, const int64_t* shape, int ndim);
     int finalize();

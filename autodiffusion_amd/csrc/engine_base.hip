@@ -35,6 +35,8 @@ adx_engine::~adx_engine() {
         if (kv.second.f32) (void)hipFree(kv.second.f32);
         if (kv.second.bf16) (void)hipFree(kv.second.bf16);
         if (kv.second.bf16lo) (void)hipFree(kv.second.bf16lo);
+        if (kv.second.blk) (void)hipFree(kv.second.blk);
+        if (kv.second.blk_lo) (void)hipFree(kv.second.blk_lo);
     }
     if (ws) (void)hipFree(ws);
     if (stage_buf) (void)hipFree(stage_buf);
@@ -85,6 +87,10 @@ LinearArgs adx_engine::lin(const float* X, int64_t ldx, const std::string& wname
     a.act = act;
     a.prec = prec;
     a.xstage = xstage; a.xstage_bytes = xstage_bytes;
+    if (prec != ADX_PREC_F32) {
+        const Param* p = find(wname);
+        if (p && p->blk && row0 == 0 && p->shape.size() == 2 && N == p->shape[0] && K == p->shape[1]) { a.Wblk = p->blk; a.Wblk_lo = p->blk_lo; }
+    }
     return a;
 }
 
@@ -102,7 +108,9 @@ int adx_engine::set_tensor(const char* name, const float* data, const int64_t* s
         if (p.f32) (void)hipFree(p.f32);
         if (p.bf16) (void)hipFree(p.bf16);
         if (p.bf16lo) (void)hipFree(p.bf16lo);
-        p.f32 = nullptr; p.bf16 = nullptr; p.bf16lo = nullptr;
+        if (p.blk) (void)hipFree(p.blk);
+        if (p.blk_lo) (void)hipFree(p.blk_lo);
+        p.f32 = nullptr; p.bf16 = nullptr; p.bf16lo = nullptr; p.blk = nullptr; p.blk_lo = nullptr;
         ADX_HIP(hipMalloc(&p.f32, sizeof(float) * numel));
         if (ndim >= 2) {
             ADX_HIP(hipMalloc(&p.bf16, sizeof(uint16_t) * numel));
@@ -127,6 +135,21 @@ int adx_engine::finalize() {
             for (int64_t v : p->shape) got += std::to_string(v) + ",";
             for (int64_t v : s.shape) want += std::to_string(v) + ",";
             return fail(ADX_EINVAL, "finalize: parameter '" + s.name + "' has shape [" + got + "] expected [" + want + "]");
+        }
+    }
+    if (wants_blocked_weights()) {
+        ADX_HIP(hipSetDevice(device));
+        for (auto& kv : params) {
+            Param& p = kv.second;
+            if (p.shape.size() != 2 || !p.bf16) continue;
+            const int64_t N = p.shape[0], K = p.shape[1];
+            if ((K % 32) != 0 || N * K >= ((int64_t)1 << 31)) continue;
+            if (!p.blk) {
+                ADX_HIP(hipMalloc(&p.blk, sizeof(uint16_t) * p.numel));
+                ADX_HIP(hipMalloc(&p.blk_lo, sizeof(uint16_t) * p.numel));
+            }
+            ADX_HIP(linear_block_weight(p.bf16, (int)N, (int)K, p.blk, nullptr));
+            ADX_HIP(linear_block_weight(p.bf16lo, (int)N, (int)K, p.blk_lo, nullptr));
         }
     }
     ADX_HIP(hipStreamSynchronize(nullptr));

@@ -11,6 +11,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -30,6 +31,9 @@ struct EngineDiT final : adx_engine {
           *HN2 = nullptr, *QB = nullptr, *KB = nullptr, *VB = nullptr, *ATT = nullptr, *Z0 = nullptr, *Z1 = nullptr, *FF = nullptr,
           *OB = nullptr, *XA = nullptr, *CA = nullptr, *MODF = nullptr, *XS0 = nullptr, *XS1 = nullptr, *MOUT = nullptr, *TEB = nullptr,
           *TEH1 = nullptr, *TEH2 = nullptr;
+    // bf16 operand planes ([K/16][rows][16], high halves then low halves) written by the producing kernels for the large GEMMs
+    unsigned short *SILP = nullptr, *HNP = nullptr, *Z1P = nullptr, *FFP = nullptr;
+    bool wants_blocked_weights() const override { return cfg.precision != ADX_PREC_F32; }
 
     explicit EngineDiT(const adx_model_config& c) {
         cfg = c;
@@ -101,6 +105,13 @@ struct EngineDiT final : adx_engine {
             take(&OB, R * d); take(&XA, R * d); take(&CA, R * d);
         }
         take(&XS0, R * C); take(&XS1, R * C); take(&MOUT, R * C);
+        if (!mm && cfg.precision != ADX_PREC_F32) {      // operand planes: 2 planes x 2 bytes = one float per element
+            float* p = nullptr;
+            take(&p, R * d); SILP = reinterpret_cast<unsigned short*>(p);
+            take(&p, R * d); HNP = reinterpret_cast<unsigned short*>(p);
+            take(&p, R * d); Z1P = reinterpret_cast<unsigned short*>(p);
+            take(&p, R * 4 * d); FFP = reinterpret_cast<unsigned short*>(p);
+        }
         {   // bf16 planes of the largest GEMM operands (X: R x 4d, W: 6d x 4d at most) for the staged kernel
             float* stage = nullptr;
             const size_t sb = cfg.precision == ADX_PREC_F32 ? 0 : adx::linear_stage_bytes((int)R, 6 * d, 4 * d, cfg.precision);
@@ -161,16 +172,25 @@ struct EngineDiT final : adx_engine {
         return run_stages(s_stages, s_cat, R, SE, nullptr, s);
     }
 
-    int ln_mod(const float* x, float* y, const float* mod, int ld_mod, int shift_chunk, int R, hipStream_t s) {
+    // ph: also (y == nullptr: only) store the result as operand planes of the next product (low halves with split operands)
+    void set_planes(LayerNormArgs& a, unsigned short* ph, int R) const {
+        a.ph = ph;
+        a.pl = (ph && cfg.precision == ADX_PREC_BF16X3) ? ph + (size_t)R * d : nullptr;
+    }
+
+    int ln_mod(const float* x, float* y, const float* mod, int ld_mod, int shift_chunk, int R, hipStream_t s, unsigned short* ph = nullptr) {
         LayerNormArgs a;
+        set_planes(a, ph, R);
         a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.eps = 1e-6f; a.rows = R; a.d = d;
         a.shift = mod + (int64_t)shift_chunk * d; a.scale = mod + (int64_t)(shift_chunk + 1) * d; a.ldm = ld_mod;
         ADX_HIP(layernorm(a, s));
         return ADX_OK;
     }
 
-    int ln_affine(const float* x, float* y, const std::string& p, int R, const float* gate, int ldg, const float* res, hipStream_t s) {
+    int ln_affine(const float* x, float* y, const std::string& p, int R, const float* gate, int ldg, const float* res, hipStream_t s,
+                  unsigned short* ph = nullptr) {
         LayerNormArgs a;
+        set_planes(a, ph, R);
         a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.eps = 1e-5f; a.rows = R; a.d = d;
         a.gamma = P(p + ".weight"); a.beta = P(p + ".bias");
         a.gate = gate; a.ldg = ldg; a.res = res; a.ldr = d;
@@ -188,12 +208,29 @@ struct EngineDiT final : adx_engine {
         ADX_HIP(add_vec_act(SE, te, SIL, R, d, rows_per_vec, ACT_SILU, s));
         if (!mm) {
             const int dh = d / H;
+            // Operand planes: where the staged GEMM will take a product (enough tiles, long enough K), the kernel that PRODUCES
+            // its X writes bf16 planes in the layout that GEMM copies from -- no re-layout pass, and activations that only feed
+            // a product (the 4d-wide hidden layers, the second modulated LayerNorm) never exist in fp32.
+            const int prec = cfg.precision;
+            const char* pl_env = getenv("ADX_DIT_PLANES");           // fallback / measurement switch, read per call: 0 = fp32 activations between all kernels
+            const bool planes = prec != ADX_PREC_F32 && HNP && (d % 256) == 0 && !(pl_env && pl_env[0] == '0');
+            const bool pk_d = planes && linear_planes_ok(R, 3 * d, d, prec) && linear_planes_ok(R, 4 * d, d, prec);
+            const bool pk_4d = planes && linear_planes_ok(R, d, 4 * d, prec);
+            const bool pk_sil = planes && linear_planes_ok(R, 6 * d, d, prec);
+            const bool x3 = prec == ADX_PREC_BF16X3;
+            auto use_planes = [&](LinearArgs& a, const unsigned short* ph, int K) { a.Xh = ph; a.Xl = x3 ? ph + (size_t)R * K : nullptr; };
+            auto out_planes = [&](LinearArgs& a, unsigned short* ph, int N) { a.Y = nullptr; a.Yh = ph; a.Yl = x3 ? ph + (size_t)R * N : nullptr; };
+            if (pk_sil) ADX_HIP(stage_planes(SIL, d, R, d, ACT_NONE, SILP, x3 ? SILP + (size_t)R * d : nullptr, s));
             for (int i = 0; i < NL; ++i) {
                 const std::string p = "blocks." + std::to_string(i);
-                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation.1.weight", 0, 6 * d, d, p + ".adaLN_modulation.1.bias", MOD, 6 * d, R), s));
-                ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 0, R, s));
+                LinearArgs ada = lin(SIL, d, p + ".adaLN_modulation.1.weight", 0, 6 * d, d, p + ".adaLN_modulation.1.bias", MOD, 6 * d, R);
+                if (pk_sil) use_planes(ada, SILP, d);
+                ADX_HIP(linear(ada, s));
+                ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 0, R, s, pk_d ? HNP : nullptr));
                 // post-norm ReLU encoder layer on HN
-                ADX_HIP(linear(lin(HN, d, p + ".attn.self_attn.in_proj_weight", 0, 3 * d, d, p + ".attn.self_attn.in_proj_bias", QB, 3 * d, R), s));
+                LinearArgs qkv = lin(HN, d, p + ".attn.self_attn.in_proj_weight", 0, 3 * d, d, p + ".attn.self_attn.in_proj_bias", QB, 3 * d, R);
+                if (pk_d) use_planes(qkv, HNP, d);
+                ADX_HIP(linear(qkv, s));
                 AttentionArgs at;
                 at.Q = QB; at.K = QB + d; at.V = QB + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
                 at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)S * 3 * d;
@@ -203,17 +240,25 @@ struct EngineDiT final : adx_engine {
                 LinearArgs o = lin(ATT, d, p + ".attn.self_attn.out_proj.weight", 0, d, d, p + ".attn.self_attn.out_proj.bias", Z0, d, R);
                 o.res = HN; o.ldr = d;
                 ADX_HIP(linear(o, s));
-                ADX_TRY(ln_affine(Z0, Z1, p + ".attn.norm1", R, nullptr, 0, nullptr, s));
-                ADX_HIP(linear(lin(Z1, d, p + ".attn.linear1.weight", 0, 4 * d, d, p + ".attn.linear1.bias", FF, 4 * d, R, ACT_RELU), s));
+                ADX_TRY(ln_affine(Z0, Z1, p + ".attn.norm1", R, nullptr, 0, nullptr, s, pk_d ? Z1P : nullptr));
+                LinearArgs f1 = lin(Z1, d, p + ".attn.linear1.weight", 0, 4 * d, d, p + ".attn.linear1.bias", FF, 4 * d, R, ACT_RELU);
+                if (pk_d) use_planes(f1, Z1P, d);
+                if (pk_4d) out_planes(f1, FFP, 4 * d);
+                ADX_HIP(linear(f1, s));
                 LinearArgs f2 = lin(FF, 4 * d, p + ".attn.linear2.weight", 0, d, 4 * d, p + ".attn.linear2.bias", Z0, d, R);
+                if (pk_4d) use_planes(f2, FFP, 4 * d);
                 f2.res = Z1; f2.ldr = d;
                 ADX_HIP(linear(f2, s));
                 // x = x + gate_msa * norm2(...)
                 ADX_TRY(ln_affine(Z0, HX, p + ".attn.norm2", R, MOD + 2 * d, 6 * d, HX, s));
                 // x = x + gate_mlp * gelu(W2 gelu(W1 modulate(LN(x))))
-                ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 3, R, s));
-                ADX_HIP(linear(lin(HN, d, p + ".mlp.0.weight", 0, 4 * d, d, p + ".mlp.0.bias", FF, 4 * d, R, ACT_GELU_TANH), s));
+                ADX_TRY(ln_mod(HX, pk_d ? nullptr : HN, MOD, 6 * d, 3, R, s, pk_d ? HNP : nullptr));
+                LinearArgs m1 = lin(HN, d, p + ".mlp.0.weight", 0, 4 * d, d, p + ".mlp.0.bias", FF, 4 * d, R, ACT_GELU_TANH);
+                if (pk_d) use_planes(m1, HNP, d);
+                if (pk_4d) out_planes(m1, FFP, 4 * d);
+                ADX_HIP(linear(m1, s));
                 LinearArgs m2 = lin(FF, 4 * d, p + ".mlp.2.weight", 0, d, 4 * d, p + ".mlp.2.bias", HX, d, R, ACT_GELU_TANH);
+                if (pk_4d) use_planes(m2, FFP, 4 * d);
                 m2.gate = MOD + 5 * d; m2.ldg = 6 * d; m2.res = HX; m2.ldr = d;
                 ADX_HIP(linear(m2, s));
             }

@@ -158,12 +158,14 @@ __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* 
         float v[RP][4];
         float4 g[RP], r[RP];
         float* yp[RP];
+        int pm[RP];
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             const int row = (r0 + i) * 8 + (lane >> 3), m = m_base + row;
             const int mc = m < a.M ? m : a.M - 1;                 // clamped rows are loaded and computed but not stored
             const int64_t yrow = row_of(a.ymap, mc);
-            yp[i] = m < a.M ? a.Y + yrow * a.ldy + nc : nullptr;
+            yp[i] = (m < a.M && a.Y) ? a.Y + yrow * a.ldy + nc : nullptr;
+            pm[i] = m < a.M ? m : -1;
             const float4 raw = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4);
             float4 p = zero;
             g[i] = zero; r[i] = zero;
@@ -188,6 +190,23 @@ __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* 
 #pragma unroll
         for (int i = 0; i < RP; ++i)
             if (yp[i]) *reinterpret_cast<float4*>(yp[i]) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        if (a.Yh) {             // the result as operand planes of the next product: [N/16][M][16], this lane's 4 columns = 8 bytes
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                if (pm[i] < 0) continue;
+                const int64_t o = ((int64_t)(n >> 4) * a.M + pm[i]) * 16 + (n & 15);
+                bf16x4 hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hi[e] = (__bf16)v[i][e];
+                *reinterpret_cast<bf16x4*>(a.Yh + o) = hi;
+                if (a.Yl) {
+                    bf16x4 lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(v[i][e] - (float)hi[e]);
+                    *reinterpret_cast<bf16x4*>(a.Yl + o) = lo;
+                }
+            }
+        }
     }
 }
 
@@ -599,6 +618,14 @@ __device__ __forceinline__ void dma16_unordered(const unsigned short* g, unsigne
                  : "=&s"(keep) : "s"(lds), "v"(g) : "memory");
 }
 
+// The same copy with a wave-uniform base (SGPR pair), a 32-bit byte offset per lane and a wave-uniform LDS address: no
+// vector arithmetic per copy.  m0 is restored: the compiler does not expect inline assembly to change it.
+__device__ __forceinline__ void dma16_sbase(const void* base_uniform, unsigned lane_off_bytes, unsigned lds_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_uniform), "v"(lane_off_bytes), "s"(base_uniform) : "memory");
+}
+
 struct StagedOperands {
     const unsigned short *xh, *xl, *wh, *wl;      // K-blocked planes: [K/16][M][16] and [K/16][N][16]
 };
@@ -816,7 +843,8 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
     } else { tm = lin / tiles_n; tn = lin % tiles_n; }
     const int m0 = tm * G2_TM, n0 = tn * G2_TN;
     const int M = a.M, N = a.N, K = a.K;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: everything derived from it lives in scalar registers
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 31, fc = lane >> 5;
 
@@ -828,6 +856,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
     const unsigned woff = (unsigned)min(n0 + r, N - 1) * 16u + half;
     const unsigned xstep = (unsigned)M * 16u, wstep = (unsigned)N * 16u;
     const int nk = K / GK;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem + (unsigned)wave * 1024u;       // LDS address of this wave's slab 0 in slot 0
     auto issue = [&](int kt, int slot) {             // K-step kt (clamped: steps past the end repeat the last one) -> ring slot
         unsigned char* st = smem + slot * STAGE_B + wave * 1024;
         const int kc = min(kt, nk - 1);
@@ -871,10 +900,13 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
             // MFMA groups of this step (one accumulator = one group), so that no burst of LDS reads or copy issues sits in
             // front of the first MFMA
             const unsigned char* ns = smem + nslot * STAGE_B;
-            unsigned char* st = smem + slot * STAGE_B + wave * 1024;
             const int kc = (ABL & 64) ? 0 : min(kt + R, nk - 1);    // measurement aid (64): every copy re-reads K-step 0 (L1 / L2 hits only)
-            const unsigned xo = (unsigned)kc * xstep, wo = (unsigned)kc * wstep + woff;
             constexpr int LO = G2_A_B + G2_B_B;
+            const unsigned lst = lds0 + (unsigned)(slot * STAGE_B);                  // this wave's first slab of the slot (LDS address)
+            const unsigned short* sxh = so.xh + (size_t)kc * xstep;
+            const unsigned short* swh = so.wh + (size_t)kc * wstep;
+            const unsigned short* sxl = X3 ? so.xl + (size_t)kc * xstep : nullptr;
+            const unsigned short* swl = X3 ? so.wl + (size_t)kc * wstep : nullptr;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int i = g >> 1, j = g & 1;
@@ -896,13 +928,13 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
                 }
                 }
                 if constexpr (!(ABL & 2)) {
-                if (g == 1) dma16_unordered(so.xh + xo + xoff0, st);
-                if (g == 2) dma16_unordered(so.xh + xo + xoff1, st + 4096);
-                if (g == 3) dma16_unordered(so.wh + wo, st + G2_A_B);
+                if (g == 1) dma16_sbase(sxh, 2u * xoff0, lst);
+                if (g == 2) dma16_sbase(sxh, 2u * xoff1, lst + 4096);
+                if (g == 3) dma16_sbase(swh, 2u * woff, lst + G2_A_B);
                 if constexpr (X3) {
-                    if (g == 4) dma16_unordered(so.xl + xo + xoff0, st + LO);
-                    if (g == 5) dma16_unordered(so.xl + xo + xoff1, st + LO + 4096);
-                    if (g == 6) dma16_unordered(so.wl + wo, st + LO + G2_A_B);
+                    if (g == 4) dma16_sbase(sxl, 2u * xoff0, lst + LO);
+                    if (g == 5) dma16_sbase(sxl, 2u * xoff1, lst + LO + 4096);
+                    if (g == 6) dma16_sbase(swl, 2u * woff, lst + LO + G2_A_B);
                 }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1002,14 +1034,18 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
         default: break;
     }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return hipErrorInvalidValue;
-    const size_t xe = (size_t)a.M * a.K, we = (size_t)a.N * a.K;
+    const size_t xe = a.Xh ? 0 : (size_t)a.M * a.K, we = (size_t)a.N * a.K;          // scratch layout: [X planes unless given][W planes unless given]
     unsigned short* base = reinterpret_cast<unsigned short*>(a.xstage);
     StagedOperands so;
-    unsigned short* xh = base;
-    unsigned short* xl = X3 ? base + xe : nullptr;
-    so.xh = xh; so.xl = xl;
-    const int64_t nx = (int64_t)a.M * (a.K >> 3);
-    hipLaunchKernelGGL(stage_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, a, xh, xl);
+    if (a.Xh) {
+        so.xh = a.Xh; so.xl = a.Xl;
+    } else {
+        unsigned short* xh = base;
+        unsigned short* xl = X3 ? base + xe : nullptr;
+        so.xh = xh; so.xl = xl;
+        const int64_t nx = (int64_t)a.M * (a.K >> 3);
+        hipLaunchKernelGGL(stage_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, a, xh, xl);
+    }
     if (a.Wblk) {
         so.wh = reinterpret_cast<const unsigned short*>(a.Wblk);
         so.wl = reinterpret_cast<const unsigned short*>(a.Wblk_lo);
@@ -1272,6 +1308,22 @@ static hipError_t launch_big(const LinearArgs& a, hipStream_t stream) {
 
 size_t linear_stage_bytes(int M, int N, int K, int prec) { return ((size_t)M + N) * K * 2 * (prec == PREC_BF16X3 ? 2 : 1); }
 
+bool linear_planes_ok(int M, int N, int K, int prec) {
+    if (prec != PREC_BF16 && prec != PREC_BF16X3) return false;
+    const int64_t tiles = (int64_t)((M + G2_TM - 1) / G2_TM) * ((N + G2_TN - 1) / G2_TN);
+    return M >= 256 && N >= 64 && K >= 512 && (K % 64) == 0 && (N & 3) == 0 && tiles >= 320 && (int64_t)M * K < ((int64_t)1 << 31) &&
+           (int64_t)N * K < ((int64_t)1 << 31);
+}
+
+hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream) {
+    if (!x || !hi || M <= 0 || K <= 0 || (K % 16) != 0 || (ldx & 3) != 0) return hipErrorInvalidValue;
+    LinearArgs a;
+    a.X = x; a.ldx = ldx; a.M = M; a.K = K; a.in_act = in_act;
+    const int64_t nx = (int64_t)M * (K >> 3);
+    hipLaunchKernelGGL(stage_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, a, hi, lo);
+    return hipGetLastError();
+}
+
 hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream) {
     if (!w || !out || N <= 0 || K <= 0 || (K % 32) != 0) return hipErrorInvalidValue;
     const int64_t nw = (int64_t)N * (K >> 3);
@@ -1282,6 +1334,7 @@ hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream
 
 hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     if (!linear_big_ok(a)) return hipErrorInvalidValue;
+    if (a.Yh && (!linear_vec_ok(a) || a.col_group != 0 || a.ymap.per_batch != 0 || (a.N & 15) != 0)) return hipErrorInvalidValue;
     static const int force_wm = [] { const char* e = getenv("ADX_GEMM_WM"); return e ? atoi(e) : 0; }();     // tuning knob
     // 256-row tiles halve the X traffic per flop; they need enough tiles to cover the chip (256 CUs, one workgroup each)
     const int64_t tiles256 = (int64_t)((a.M + 255) / 256) * ((a.N + TN - 1) / TN);
@@ -1296,15 +1349,21 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     // N=1536 523 against 591; single-pass bf16 M=327680 N=1024 404 against 755.  Slower at N=256 (241 against 228).
     const char* rows_env = getenv("ADX_GEMM_ROWS");             // read per call (tests switch it): 0 never, 1 whenever legal
     const int rows_mode = rows_env ? atoi(rows_env) : -1;
-    if (force_wm == 0 && rows_mode != 0 && !a.force_staged && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N && linear_vec_ok(a) &&
+    if (force_wm == 0 && rows_mode != 0 && !a.force_staged && !a.Xh && (a.K == 256 || a.K == 128 || a.K == 64) && a.N <= ROWS_MAX_N && linear_vec_ok(a) &&
         ((a.M >= 160 * 1024 && a.N >= 512) || rows_mode == 1))
         return a.prec == PREC_BF16X3 ? launch_rows<true>(a, stream) : launch_rows<false>(a, stream);
     static const bool no_glds = [] { const char* e = getenv("ADX_GEMM_NO_DMA"); return e && e[0] == '1'; }();
     const int64_t tiles_sq = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
     const char* any_env = getenv("ADX_GEMM_DMA_ANY");             // read per call (tests switch it): the staged kernel for any shape
     const bool glds_any = any_env && any_env[0] == '1';
-    if (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any || a.force_staged) && a.xstage &&
-        a.xstage_bytes >= linear_stage_bytes(a.M, a.Wblk ? 0 : a.N, a.K, a.prec) && (reinterpret_cast<uintptr_t>(a.xstage) & 15) == 0 &&
+    const size_t stage_need = linear_stage_bytes(a.Xh ? 0 : a.M, a.Wblk ? 0 : a.N, a.K, a.prec);
+    const bool stage_fits = stage_need == 0 || (a.xstage && a.xstage_bytes >= stage_need && (reinterpret_cast<uintptr_t>(a.xstage) & 15) == 0);
+    if (a.Xh) {                 // operand planes from the producing kernel: there may be no fp32 X at all, so only the staged kernel will do
+        if (!stage_fits || !linear_planes_ok(a.M, a.N, a.K, a.prec) || (a.prec == PREC_BF16X3 && !a.Xl) || a.xmap.per_batch != 0) return hipErrorInvalidValue;
+        return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);
+    }
+    if (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any || a.force_staged) && stage_fits &&
+        (a.xstage || stage_need == 0) &&
         (int64_t)a.M * a.K < ((int64_t)1 << 31) && (int64_t)a.N * a.K < ((int64_t)1 << 31))
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);
     // measured: the wave-specialised form wins for single-pass bf16 (its producers keep up with 16 MFMAs per K-step per

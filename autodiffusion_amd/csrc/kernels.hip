@@ -259,6 +259,7 @@ hipError_t linear(const LinearArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
     static const bool small_only = [] { const char* e = getenv("ADX_LINEAR_SMALL"); return e && e[0] == '1'; }();   // tuning knob
     if (!small_only && linear_big_ok(a)) return linear_big(a, stream);
+    if (a.Xh || a.Yh) return hipErrorInvalidValue;              // operand planes exist for the large-tile kernels only
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN);
     if (a.prec == PREC_BF16X3) {
         if (!a.Wlo) return hipErrorInvalidValue;
@@ -342,7 +343,21 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs 
         if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
         if (gt) { const float4 g = gt[c]; o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
         if (rs) { const float4 r = rs[c]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
-        y[c] = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.y) y[c] = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.ph) {             // K-blocked planes [d/16][rows][16]: this lane's 4 values are columns 4c .. 4c+3
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+            const int64_t off = ((int64_t)(c >> 2) * a.rows + row) * 16 + ((4 * c) & 15);
+            bf16x4_t hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hi[e] = (__bf16)o[e];
+            *reinterpret_cast<bf16x4_t*>(a.ph + off) = hi;
+            if (a.pl) {
+                bf16x4_t lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(o[e] - (float)hi[e]);
+                *reinterpret_cast<bf16x4_t*>(a.pl + off) = lo;
+            }
+        }
     }
 }
 
@@ -355,6 +370,8 @@ hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
                      (!a.shift || ((a.ldm & 3) == 0 && aligned16(a.shift) && aligned16(a.scale))) &&
                      (!a.gate || ((a.ldg & 3) == 0 && aligned16(a.gate))) && (!a.res || ((a.ldr & 3) == 0 && aligned16(a.res)));
     const dim3 grid((a.rows + 3) / 4), block(256);
+    if (a.ph && (!vec || a.ymap.per_batch != 0)) return hipErrorInvalidValue;       // planes come from the register-resident kernel only
+    if (!a.y && !a.ph) return hipErrorInvalidValue;
     if (vec) {
         switch (a.d / 256) {
             case 1: hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, stream, a); return hipGetLastError();
@@ -366,6 +383,7 @@ hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
             default: break;
         }
     }
+    if (a.ph || !a.y) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }
