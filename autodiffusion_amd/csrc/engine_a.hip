@@ -65,6 +65,13 @@ struct EngineA final : adx_engine {
     int tail_split = 0;                // its maps on memory rows run on split-bf16 operands (bf16 precision modes) instead of fp32 MFMAs
     void* tailm_image = nullptr;
     float* tailm_vecs = nullptr;
+    // The decoder-side kernel (tail) of step k only depends on the encoder-side kernels of step k and on x_k, and the
+    // encoder side does not depend on x at all: the tail of step k runs on a second stream under the encoder kernels of
+    // step k + 1.  Its inputs (the last encoder layer's attention output and residual rows) are double-buffered by step parity.
+    float *ATTb = nullptr;                    // second buffer of ATT (XB is the second buffer of XA)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+    bool overlap_ok = false;
 
     ~EngineA() override {
         if (tqkv0) (void)hipFree(tqkv0);
@@ -74,6 +81,9 @@ struct EngineA final : adx_engine {
         if (tx0) (void)hipFree(tx0);
         if (tailm_image) (void)hipFree(tailm_image);
         if (tailm_vecs) (void)hipFree(tailm_vecs);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        for (hipEvent_t e : ev_enc) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_tail) if (e) (void)hipEventDestroy(e);
     }
 
     void on_workspace_realloc() override { maps_batch = -1; }     // the map embedding and its caches lived in the old workspace
@@ -150,6 +160,7 @@ struct EngineA final : adx_engine {
             take(&ATT0, (size_t)B * std::max<size_t>(steps.size(), 1) * d);
             if (split_cache) take(&STM, BL * H * 6);
             take(&KV1, BL * 2 * d);
+            take(&ATTb, BL * d);
         }
         *bytes = off;
         return ADX_OK;
@@ -263,17 +274,17 @@ struct EngineA final : adx_engine {
     }
 
     // Rest of the last encoder layer + decoder + head + scheduler update, one launch.
-    int launch_tail(int B, const float* x, const float* z, const StepCoef* coef, float* x_next, float* out, hipStream_t s) {
+    int launch_tail(int B, const float* x, const float* z, const StepCoef* coef, float* x_next, float* out, hipStream_t s, int par = 0) {
         if (tail_mfma_ok) {
             TailMfmaArgs t;
-            t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = z; t.coef = coef;
+            t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = par ? ATTb : ATT; t.x1 = par ? XB : XA; t.x = x; t.z = z; t.coef = coef;
             t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_split;
             t.pos = P("pos_emb");
             ADX_HIP(tail_mfma(t, s));
             return ADX_OK;
         }
         TailArgs t = tail_tpl;
-        t.w = tail_w; t.att1 = ATT; t.x1 = XA; t.x = x; t.z = z; t.coef = coef;
+        t.w = tail_w; t.att1 = par ? ATTb : ATT; t.x1 = par ? XB : XA; t.x = x; t.z = z; t.coef = coef;
         t.x_next = x_next; t.model_out = out;
         t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
         ADX_HIP(tail_a(t, s));
@@ -403,14 +414,14 @@ struct EngineA final : adx_engine {
         return ADX_OK;
     }
 
-    EncRowsArgs rows_args(int B, int step) const {
+    EncRowsArgs rows_args(int B, int step, int par = 0) const {
         EncRowsArgs r;
         r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.packed = reinterpret_cast<const float4*>(PK);
         r.att0 = ATT0 + (int64_t)step * B * d;     // [step][B][d] for the batch of this call
         r.x0_time = tx0 + (int64_t)step * d;
         r.key0 = tqkv0 + (int64_t)step * 3 * d + d;
         r.image = rows_image; r.vecs = rows_vecs;
-        r.kv = KV1; r.ldkv = 2 * d; r.x1 = XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
+        r.kv = KV1; r.ldkv = 2 * d; r.x1 = par ? XB : XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
         return r;
     }
@@ -452,8 +463,9 @@ struct EngineA final : adx_engine {
 
     // ---------------------------------------------------------------------------------- the network
     // last encoder layer on the fused path: queries of the T+1 visible rows (in QKV) against the compact K | V rows
-    AttentionArgs fused_attn_args(int B) const {
+    AttentionArgs fused_attn_args(int B, int par = 0) const {
         AttentionArgs at = enc_attn_args(B, T + 1);
+        if (par) at.O = ATTb;
         at.K = KV1; at.V = KV1 + d; at.ldk = at.ldv = 2 * d; at.k_batch_stride = at.v_batch_stride = (int64_t)L * 2 * d;
         return at;
     }
@@ -629,6 +641,15 @@ struct EngineA final : adx_engine {
         if (B <= 0) { set_error(std::string(who) + ": batch must be positive"); return ADX_EINVAL; }
         ADX_HIP(hipSetDevice(device));
         ADX_TRY(reserve(B));
+        if (fused && (tail_ok || tail_mfma_ok) && !side_stream) {        // never created inside a capture
+            ADX_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                ADX_HIP(hipEventCreateWithFlags(&ev_enc[i], hipEventDisableTiming));
+                ADX_HIP(hipEventCreateWithFlags(&ev_tail[i], hipEventDisableTiming));
+            }
+            const char* no = getenv("ADX_NO_OVERLAP");                   // fallback switch: every kernel of a step on one stream
+            overlap_ok = !(no && no[0] == '1');
+        }
         return ADX_OK;
     }
 
@@ -665,7 +686,39 @@ struct EngineA final : adx_engine {
         float* xc = XS0; float* xn = XS1;
         if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, s));
         else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, s));
-        for (size_t k = 0; k < steps.size(); ++k) {
+        // Measured (frame_stack 10, one MI355X, trajectories/s with / without): B=512 9810 / 8040, B=1024 11100 / 9130, B=2048 10830 / 10950,
+        // B=4096 10940 / 11530 -- below ~2k scenarios the one-wavefront-per-scenario tail leaves the chip mostly idle and hides
+        // under the encoder kernels; above, both fill the chip and only disturb each other.
+        const bool overlap = cached && fused && (tail_ok || tail_mfma_ok) && overlap_ok && !profiling && side_stream && B <= 1536;
+        if (overlap) {
+            // stream s: encoder rows + last-layer attention of step k (buffers of parity k & 1);
+            // side stream: tail of step k, after its encoder kernels and (stream order) after the tail of step k - 1.
+            // The encoder kernels of step k reuse the buffers the tail of step k - 2 read: they wait for it.
+            const size_t n_steps = steps.size();
+            for (size_t k = 0; k < n_steps; ++k) {
+                const int par = (int)(k & 1);
+                const int zi = (int)steps[k].z_index;
+                const float* z = nullptr;
+                if (zi >= 0 && steps[k].c3 != 0.f) {
+                    if (1 + zi >= n_noise) { set_error("sample_a: schedule draws more noise tensors than were supplied"); return ADX_EINVAL; }
+                    z = noise + (int64_t)(1 + zi) * n;
+                }
+                if (k >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
+                ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s));
+                ADX_HIP(attention_few_queries(fused_attn_args(B, par), s));
+                ADX_HIP(hipEventRecord(ev_enc[par], s));
+                ADX_HIP(hipStreamWaitEvent(side_stream, ev_enc[par], 0));
+                ADX_TRY(launch_tail(B, xc, z, steps_dev + k, xn, MOUT, side_stream, par));
+                if (trace_x) ADX_HIP(copy2d(xc, n, 0, trace_x + k * n, n, 1, (int)n, side_stream));
+                if (trace_out) ADX_HIP(copy2d(MOUT, n, 0, trace_out + k * n, n, 1, (int)n, side_stream));
+                ADX_HIP(hipEventRecord(ev_tail[par], side_stream));
+                float* tmp = xc; xc = xn; xn = tmp;
+            }
+            // join: everything after the loop (un-normalise, the next chunk) is ordered behind the last two tails
+            ADX_HIP(hipStreamWaitEvent(s, ev_tail[(n_steps - 1) & 1], 0));
+            if (n_steps >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[(n_steps - 2) & 1], 0));
+        }
+        for (size_t k = 0; !overlap && k < steps.size(); ++k) {
             if (!fused) ADX_TRY(set_time(B, temb_table + k * d, 0, s));   // the fused path reads the time token from tables
             const int zi = (int)steps[k].z_index;
             const float* z = nullptr;

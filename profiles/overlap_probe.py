@@ -11,7 +11,7 @@ import bench  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")
 da = bench.build_model(dev, "bf16x3")
-maps, prior, noise = bench.make_inputs(B, 0, dev)
+maps, prior, noise = bench.make_inputs(B, 0, dev, 1)
 out = torch.empty(B, 80, 4, device=dev)
 da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
 torch.cuda.synchronize()
