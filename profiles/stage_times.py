@@ -12,7 +12,7 @@ prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 dev = torch.device("cuda:0")
 da = bench.build_model(dev, prec)
-maps, prior, noise = bench.make_inputs(B, 0, dev)
+maps, prior, noise = bench.make_inputs(B, 0, dev, 1)
 out = torch.empty(B, 80, 4, device=dev)
 da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
 torch.cuda.synchronize()
