@@ -349,6 +349,50 @@ ADX_API int adx_op_linear_staged(const float* x, const void* w, const float* bia
 
 ADX_API size_t adx_linear_stage_bytes(int M, int N, int K, int prec) { return linear_stage_bytes(M, N, K, prec); }
 
+// Operands kept in the staged kernel's own layout across calls: K-blocked bf16 planes [K/16][rows][16], the high-half plane
+// followed by the low-half plane under ADX_PREC_BF16X3.  A caller that multiplies the same X or W more than once (or whose
+// producer can write the planes) pays the re-layout once and then launches the product kernel alone.
+ADX_API size_t adx_linear_planes_bytes(int rows, int K, int prec) { return (size_t)rows * K * 2 * (prec == ADX_PREC_BF16X3 ? 2 : 1); }
+
+ADX_API int adx_op_stage_planes(const float* x, int M, int K, int prec, void* planes, void* stream) {
+    if (!x || !planes) return fail(ADX_EINVAL, "stage_planes: null pointer");
+    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "stage_planes: bf16 precisions only");
+    if (M <= 0 || K <= 0 || (K % 16) != 0 || (reinterpret_cast<uintptr_t>(planes) & 15) || (reinterpret_cast<uintptr_t>(x) & 15))
+        return fail(ADX_EINVAL, "stage_planes: K must be a multiple of 16 and both pointers 16-byte aligned");
+    unsigned short* hi = reinterpret_cast<unsigned short*>(planes);
+    return done(stage_planes(x, K, M, K, ACT_NONE, hi, prec == ADX_PREC_BF16X3 ? hi + (size_t)M * K : nullptr, (hipStream_t)stream), "stage_planes");
+}
+
+ADX_API int adx_op_block_weight(const void* w, int N, int K, int prec, void* blocked, void* stream) {
+    if (!w || !blocked) return fail(ADX_EINVAL, "block_weight: null pointer");
+    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "block_weight: bf16 precisions only");
+    if (N <= 0 || K <= 0 || (K % 32) != 0 || (reinterpret_cast<uintptr_t>(blocked) & 15) || (reinterpret_cast<uintptr_t>(w) & 15))
+        return fail(ADX_EINVAL, "block_weight: K must be a multiple of 32 and both pointers 16-byte aligned");
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(w);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(blocked);
+    hipError_t e = linear_block_weight(src, N, K, dst, (hipStream_t)stream);
+    if (e == hipSuccess && prec == ADX_PREC_BF16X3) e = linear_block_weight(src + (size_t)N * K, N, K, dst + (size_t)N * K, (hipStream_t)stream);
+    return done(e, "block_weight");
+}
+
+ADX_API int adx_op_linear_planes(const void* x_planes, const void* w_blocked, const float* bias, float* y, int M, int N, int K, int act,
+                                 int prec, void* stream) {
+    if (!x_planes || !w_blocked || !y) return fail(ADX_EINVAL, "linear_planes: null pointer");
+    if (!linear_planes_ok(M, N, K, prec))
+        return fail(ADX_EINVAL, "linear_planes: needs a bf16 precision, M >= 256, N >= 64 and a multiple of 4, K >= 512 and a multiple of 64, "
+                                "and at least 320 tiles of 256 x 128");
+    if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(w_blocked) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+        (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+        return fail(ADX_EINVAL, "linear_planes: operands must be 16-byte aligned");
+    LinearArgs a;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(x_planes);
+    const uint16_t* wh = reinterpret_cast<const uint16_t*>(w_blocked);
+    a.Xh = xh; a.Wblk = wh; a.W = wh;                  // W / Wlo only satisfy the shape checks: with both operands staged nothing reads them
+    if (prec == ADX_PREC_BF16X3) { a.Xl = xh + (size_t)M * K; a.Wblk_lo = wh + (size_t)N * K; a.Wlo = a.Wblk_lo; }
+    a.ldx = K; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
+    return done(linear(a, (hipStream_t)stream), "linear_planes");
+}
+
 ADX_API int adx_op_select_modes(const float* traj, int B, int M, int L, int D, int k, int em_iter, float* modes, float* weights,
                                 void* stream) {
     if (!traj || !modes || !weights) return fail(ADX_EINVAL, "select_modes: null pointer");

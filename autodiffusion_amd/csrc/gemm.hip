@@ -817,7 +817,10 @@ __device__ __forceinline__ void load_frags2(Frags<X3>& f, const unsigned char* s
     }
 }
 
-template <bool X3, int ABL>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool X3, int ABL, int S = 1>
 __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a, const StagedOperands so, int tiles_n, int n_tiles, int pw) {
     constexpr int STAGE_B = (X3 ? 2 : 1) * (G2_A_B + G2_B_B);                  // 24 KB / 12 KB
     constexpr int R = X3 ? 3 : 6;                                              // 72 KB
@@ -880,86 +883,101 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+    // Ring discipline with S K-steps per barrier (R >= 2 S slots, step k lives in slot k % R).  At the barrier that opens the
+    // iteration of steps kt .. kt + S - 1, step kt is in registers, everybody's copies of steps kt + 1 .. kt + S have landed
+    // and nobody reads the slots of steps kt - S + 1 .. kt any more: those are refilled with steps kt + R - S + 1 .. kt + R
+    // while the iteration multiplies.  A wave may keep its copies of the youngest R - 2 S steps in flight across the barrier.
+    static_assert(R >= 2 * S, "ring too short for this many K-steps per barrier");
 #pragma unroll
-    for (int t = 0; t < R; ++t) issue(t, t);
-    // all but the (R - 1) youngest steps of this wave's copies have landed: step 0
-    if constexpr (X3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    for (int t = 0; t <= R - S; ++t) issue(t, t);
+    wait_vmcnt<(R - S) * P>();                       // step 0 has landed
     __builtin_amdgcn_s_barrier();
     Frags<X3> f0, f1;
     load_frags2<X3>(f0, smem, wr, wc, fr, fc);
     __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0)
     int slot = 0;                                    // ring slot of step kt
-    auto step = [&](int kt, Frags<X3>& cur, Frags<X3>& nxt) {
-        // this wave's copies of step kt + 1 have landed (the R - 2 younger steps may still fly) ...
-        if constexpr (X3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        // ... and so have everybody's; everybody holds step kt in registers, so its slot can be refilled
-        __builtin_amdgcn_s_barrier();
-        const int nslot = slot + 1 == R ? 0 : slot + 1;
-        if constexpr (ABL & 16) {
-            // fine-grained form: the fragment reads of the next step and the copies of step kt + R are spread between the
-            // MFMA groups of this step (one accumulator = one group), so that no burst of LDS reads or copy issues sits in
-            // front of the first MFMA
-            const unsigned char* ns = smem + nslot * STAGE_B;
-            const int kc = (ABL & 64) ? 0 : min(kt + R, nk - 1);    // measurement aid (64): every copy re-reads K-step 0 (L1 / L2 hits only)
-            constexpr int LO = G2_A_B + G2_B_B;
-            const unsigned lst = lds0 + (unsigned)(slot * STAGE_B);                  // this wave's first slab of the slot (LDS address)
-            const unsigned short* sxh = so.xh + (size_t)kc * xstep;
-            const unsigned short* swh = so.wh + (size_t)kc * wstep;
-            const unsigned short* sxl = X3 ? so.xl + (size_t)kc * xstep : nullptr;
-            const unsigned short* swl = X3 ? so.wl + (size_t)kc * wstep : nullptr;
+    constexpr int LO = G2_A_B + G2_B_B;
+    // one K-step: its MFMA groups (one accumulator = one group) with the fragment reads of the next step (slot rs) and the copies
+    // of K-step kc into slot ds spread between them, so that no burst of LDS reads or copy issues sits in front of an MFMA
+    auto sub = [&](bool live, Frags<X3>& cur, Frags<X3>& nxt, int rs, int ds, int kc) {
+        const unsigned char* ns = smem + rs * STAGE_B;
+        const unsigned lst = lds0 + (unsigned)(ds * STAGE_B);                    // this wave's first slab of the slot (LDS address)
+        const unsigned short* sxh = so.xh + (size_t)kc * xstep;
+        const unsigned short* swh = so.wh + (size_t)kc * wstep;
+        const unsigned short* sxl = X3 ? so.xl + (size_t)kc * xstep : nullptr;
+        const unsigned short* swl = X3 ? so.wl + (size_t)kc * wstep : nullptr;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int i = g >> 1, j = g & 1;
-                // reads: g 0: bh0, ah0 | 1: bh1, bl0/ah1 | ...   (order: what the next step's first groups need comes first)
-                if constexpr (!(ABL & 1)) {
-                if (g == 0) { nxt.bh[0] = *reinterpret_cast<const bf16x8*>(ns + G2_A_B + gswz(wc * 64 + fr, fc));
-                              nxt.ah[0] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + fr, fc)); }
-                if (g == 1) { nxt.bh[1] = *reinterpret_cast<const bf16x8*>(ns + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
-                              nxt.ah[1] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 32 + fr, fc)); }
-                if (g == 2) { nxt.ah[2] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 64 + fr, fc));
-                              nxt.ah[3] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 96 + fr, fc)); }
-                if constexpr (X3) {
-                    if (g == 3) { nxt.bl[0] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + fr, fc));
-                                  nxt.al[0] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + fr, fc)); }
-                    if (g == 4) { nxt.bl[1] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
-                                  nxt.al[1] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 32 + fr, fc)); }
-                    if (g == 5) nxt.al[2] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 64 + fr, fc));
-                    if (g == 6) nxt.al[3] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 96 + fr, fc));
-                }
-                }
-                if constexpr (!(ABL & 2)) {
-                if (g == 1) dma16_sbase(sxh, 2u * xoff0, lst);
-                if (g == 2) dma16_sbase(sxh, 2u * xoff1, lst + 4096);
-                if (g == 3) dma16_sbase(swh, 2u * woff, lst + G2_A_B);
-                if constexpr (X3) {
-                    if (g == 4) dma16_sbase(sxl, 2u * xoff0, lst + LO);
-                    if (g == 5) dma16_sbase(sxl, 2u * xoff1, lst + LO + 4096);
-                    if (g == 6) dma16_sbase(swl, 2u * woff, lst + LO + G2_A_B);
-                }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(ABL & 4)) {
+        for (int g = 0; g < 8; ++g) {
+            const int i = g >> 1, j = g & 1;
+            // reads: g 0: bh0, ah0 | 1: bh1, ah1 | ...   (order: what the next step's first groups need comes first)
+            if constexpr (!(ABL & 1)) {
+            if (g == 0) { nxt.bh[0] = *reinterpret_cast<const bf16x8*>(ns + G2_A_B + gswz(wc * 64 + fr, fc));
+                          nxt.ah[0] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + fr, fc)); }
+            if (g == 1) { nxt.bh[1] = *reinterpret_cast<const bf16x8*>(ns + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
+                          nxt.ah[1] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 32 + fr, fc)); }
+            if (g == 2) { nxt.ah[2] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 64 + fr, fc));
+                          nxt.ah[3] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 96 + fr, fc)); }
+            if constexpr (X3) {
+                if (g == 3) { nxt.bl[0] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + fr, fc));
+                              nxt.al[0] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + fr, fc)); }
+                if (g == 4) { nxt.bl[1] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
+                              nxt.al[1] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 32 + fr, fc)); }
+                if (g == 5) nxt.al[2] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 64 + fr, fc));
+                if (g == 6) nxt.al[3] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 96 + fr, fc));
+            }
+            }
+            if constexpr (!(ABL & 2)) {
+            if (g == 1) dma16_sbase(sxh, 2u * xoff0, lst);
+            if (g == 2) dma16_sbase(sxh, 2u * xoff1, lst + 4096);
+            if (g == 3) dma16_sbase(swh, 2u * woff, lst + G2_A_B);
+            if constexpr (X3) {
+                if (g == 4) dma16_sbase(sxl, 2u * xoff0, lst + LO);
+                if (g == 5) dma16_sbase(sxl, 2u * xoff1, lst + LO + 4096);
+                if (g == 6) dma16_sbase(swl, 2u * woff, lst + LO + G2_A_B);
+            }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) {
+            if (live) {
                 if constexpr (X3) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl[j], acc[i][j], 0, 0, 0);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh[j], acc[i][j], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
-            if (!(ABL & 2)) issue(kt + R, slot);
-            if (!(ABL & 1)) load_frags2<X3>(nxt, smem + nslot * STAGE_B, wr, wc, fr, fc);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 4)) mfma_frags<X3>(acc, cur);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        slot = nslot;
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // the next step's fragments are in registers
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, f0, f1);
-        step(kt + 1, f1, f0);
+    // the iteration of steps kt .. kt + S - 1: fa holds step kt on entry; step kt + S ends up in fa (S even) or fb (S odd)
+    auto iter = [&](int kt, Frags<X3>& fa, Frags<X3>& fb) {
+        wait_vmcnt<(R - 2 * S) * P>();
+        __builtin_amdgcn_s_barrier();
+        if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                int rs = slot + t + 1; if (rs >= R) rs -= R;
+                int ds = slot + t + 1 - S; if (ds < 0) ds += R;
+                const int kc = (ABL & 64) ? 0 : min(kt + R - S + 1 + t, nk - 1);     // measurement aid (64): every copy re-reads K-step 0 (L1 / L2 hits only)
+                const bool live = (S == 1) || (kt + t < nk);                          // K-steps past the end (nk not a multiple of S) multiply nothing
+                if (t & 1) sub(live, fb, fa, rs, ds, kc); else sub(live, fa, fb, rs, ds, kc);
+            }
+        } else {
+            static_assert((ABL & 16) || S == 1, "the un-interleaved step exists for one K-step per barrier only");
+            const int nslot = slot + 1 == R ? 0 : slot + 1;
+            if (!(ABL & 2)) issue(kt + R, slot);
+            if (!(ABL & 1)) load_frags2<X3>(fb, smem + nslot * STAGE_B, wr, wc, fr, fc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 4)) mfma_frags<X3>(acc, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        slot += S; if (slot >= R) slot -= R;
+    };
+    for (int kt = 0; kt < nk; kt += 2 * S) {
+        iter(kt, f0, f1);
+        if (kt + S < nk) { if constexpr ((S & 1) != 0) iter(kt + S, f1, f0); else iter(kt + S, f0, f1); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // every wave is done reading, no copy is in flight
@@ -1079,6 +1097,13 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
             case 27: kern2 = &linear_glds2_kernel<X3, 27>; break;
             case 80: kern2 = &linear_glds2_kernel<X3, 80>; break;
             default: break;
+        }
+        if constexpr (!X3) {            // single-pass bf16 can walk its 6-slot ring 2 or 3 K-steps per barrier.  Measured (M=20480 N=4096 K=1024,
+            // product kernel alone): 1 step 226.6 us, 2 steps 232.8, 3 steps 247.0 -- the barrier is not what limits this kernel
+            const char* ks_env = getenv("ADX_GLDS_KSTEPS");      // tuning knob, read per call
+            const int ks = ks_env ? atoi(ks_env) : 1;
+            if (abl == 0 && ks == 2) kern2 = &linear_glds2_kernel<false, 16, 2>;
+            if (abl == 0 && ks == 3) kern2 = &linear_glds2_kernel<false, 16, 3>;
         }
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess)
             return hipErrorInvalidValue;

@@ -59,6 +59,38 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return y
 
 
+def stage_planes(x: torch.Tensor, precision: str) -> torch.Tensor:
+    """K-blocked bf16 planes of an fp32 (M, K) activation, the X operand form of ``linear_planes``."""
+    lib = _lib.load()
+    x = f32c(x)
+    K = x.shape[-1]
+    M = x.numel() // K
+    prec = _lib.PRECISIONS[precision]
+    out = torch.empty(int(lib.adx_linear_planes_bytes(M, K, prec)), dtype=torch.uint8, device=x.device)
+    check(lib.adx_op_stage_planes(ptr(x), M, K, prec, ptr(out), current_stream()), "stage_planes")
+    return out
+
+
+def block_weight(w_prepared: torch.Tensor, N: int, K: int, precision: str) -> torch.Tensor:
+    """K-blocked form of a weight that ``prepare_weight`` returned, the W operand form of ``linear_planes``."""
+    lib = _lib.load()
+    prec = _lib.PRECISIONS[precision]
+    out = torch.empty(int(lib.adx_linear_planes_bytes(N, K, prec)), dtype=torch.uint8, device=w_prepared.device)
+    check(lib.adx_op_block_weight(ptr(w_prepared), N, K, prec, ptr(out), current_stream()), "block_weight")
+    return out
+
+
+def linear_planes(x_planes: torch.Tensor, w_blocked: torch.Tensor, bias: Optional[torch.Tensor], M: int, N: int, K: int,
+                  act: int = _lib.ACT_NONE, precision: str = "bf16x3", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``act(x w^T + bias)`` from operands already in the staged kernel's layout: only the product kernel runs."""
+    lib = _lib.load()
+    b = f32c(bias) if bias is not None else None
+    y = out if out is not None else torch.empty(M, N, device=x_planes.device, dtype=torch.float32)
+    check(lib.adx_op_linear_planes(ptr(x_planes), ptr(w_blocked), ptr(b), ptr(y), M, N, K, act, _lib.PRECISIONS[precision], current_stream()),
+          "linear_planes")
+    return y
+
+
 def linear_stage_bytes(M: int, N: int, K: int, precision: str) -> int:
     return int(_lib.load().adx_linear_stage_bytes(int(M), int(N), int(K), _lib.PRECISIONS[precision]))
 

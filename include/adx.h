@@ -69,6 +69,18 @@ int adx_op_linear(const float* x, const void* w, const float* bias, float* y, in
 int adx_op_linear_staged(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act,
                          int prec, void* workspace, size_t workspace_bytes, void* stream);
 size_t adx_linear_stage_bytes(int M, int N, int K, int prec);
+/* The staged product with operands kept in its own layout across calls (same reference call sites as adx_op_linear; the
+ * layers of libs/diffusionTransformer.py:63-76,134-165 multiply the same activations by several weights and the same weights
+ * at every sampling step).  A plane set is K-blocked bf16, [K/16][rows][16], adx_linear_planes_bytes(rows, K, prec) bytes,
+ * 16-byte aligned: the high halves, followed under ADX_PREC_BF16X3 by the low halves.  adx_op_stage_planes writes the
+ * planes of fp32 x[M][K]; adx_op_block_weight those of a weight in adx_op_linear's `w` form; adx_op_linear_planes multiplies
+ * two plane sets (M >= 256, N >= 64 and a multiple of 4, K >= 512 and a multiple of 64, at least 320 tiles of 256 x 128;
+ * anything else is ADX_EINVAL).  Results equal adx_op_linear_staged's bit for bit. */
+size_t adx_linear_planes_bytes(int rows, int K, int prec);
+int adx_op_stage_planes(const float* x, int M, int K, int prec, void* planes, void* stream);
+int adx_op_block_weight(const void* w, int N, int K, int prec, void* blocked, void* stream);
+int adx_op_linear_planes(const void* x_planes, const void* w_blocked, const float* bias, float* y, int M, int N, int K, int act,
+                         int prec, void* stream);
 /* No counterpart in the reference.  For callers that cannot allocate device memory (code under hipGraph capture, tight serving
  * loops, harnesses that forbid hipMalloc): adx_op_linear_staged with the staging workspace taken from a fixed device array inside
  * the library (adx_noalloc_scratch_bytes() = 64 MiB per GPU, held until the process ends) -- the call allocates nothing.  Always

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Staged (LDS-DMA) GEMM: the one-workgroup-per-CU form (ADX_GLDS_FORM=1, 256x256 tiles, 8 waves) against the two-workgroups-per-CU
 form (ADX_GLDS_FORM=2, 256x128 tiles, 4 waves each), alternating in one warm process; events on the launch stream.  Also checks
-that the two forms return the same bits and that both agree with an fp64 product of the same operands."""
+that the two forms return the same bits and that both agree with an fp64 product of the same operands.  Form times include
+the re-layout kernels of X and W; the "planes" line is form 2's product kernel on operands already in planes."""
 import os
 import sys
 
@@ -47,6 +48,26 @@ for prec in sys.argv[1:] or ["bf16x3", "bf16"]:
                 e.record()
                 torch.cuda.synchronize()
                 best[f] = min(best[f], s.elapsed_time(e) * 100)
+        if "2" in forms and K >= 512:            # the product kernel alone, operands already in planes (what the decoder launches)
+            os.environ["ADX_GLDS_FORM"] = "2"
+            xp, wp, y = ops.stage_planes(x, prec), ops.block_weight(w, N, K, prec), torch.empty(M, N, device=dev)
+            for _ in range(20):
+                ops.linear_planes(xp, wp, b, M, N, K, precision=prec, out=y)
+            assert torch.equal(y, ys["2"])
+            us = float("inf")
+            for _ in range(3):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                s.record()
+                for _ in range(10):
+                    ops.linear_planes(xp, wp, b, M, N, K, precision=prec, out=y)
+                e.record()
+                torch.cuda.synchronize()
+                us = min(us, s.elapsed_time(e) * 100)
+            tf = 2.0 * M * N * K / us / 1e6
+            print(f"{prec:7s} planes  M={M:6d} N={N:5d} K={K:5d}  {us:8.1f} us  {tf:7.1f} TFLOP/s  executed {tf * mult:7.1f} = {tf * mult / 25.0:5.1f} % of 2.5 PFLOP/s"
+                  f"  (form 2's product kernel alone; bits equal to form 2: True)", flush=True)
+            del xp, wp, y
         for f in forms:
             us = best[f]
             tf = 2.0 * M * N * K / us / 1e6

@@ -41,8 +41,8 @@ if [ $part = all ] || [ $part = gemm ]; then
     echo "# rocprofv3 --pmc passes over profiles/gemm_forms.py (ADX_FORMS=2: the two-workgroups-per-CU staged kernel), M=20480 N=4096 K=1024, per-launch averages" > $O/pmc_gemm.txt
     for p in bf16x3 bf16; do
         echo "## $p" >> $O/pmc_gemm.txt
-        ADX_FORMS=2 pmc pmc_gemm "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" linear_glds2 python3 profiles/gemm_forms.py $p
-        ADX_FORMS=2 pmc pmc_gemm "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" linear_glds2 python3 profiles/gemm_forms.py $p
+        ADX_FORMS=2 pmc pmc_gemm "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAIT_INST_LDS" linear_glds python3 profiles/gemm_forms.py $p
+        ADX_FORMS=2 pmc pmc_gemm "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" linear_glds python3 profiles/gemm_forms.py $p
     done
     unset ADX_GEMM_SHAPE
     cat $O/pmc_gemm.txt

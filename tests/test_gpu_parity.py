@@ -109,6 +109,36 @@ def test_op_linear_staged(dev, M, N, K, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("M,N,K", [(10000, 4100, 512), (20480, 1024, 1024)])
+def test_op_linear_planes(dev, M, N, K, prec):
+    """Operands kept as K-blocked planes across calls (adx_op_stage_planes, adx_op_block_weight, adx_op_linear_planes): the
+    product kernel alone returns the bits of the staged entry, ragged M and N included; shapes the kernel does not take and
+    misaligned plane pointers are refused."""
+    from autodiffusion_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ws = torch.empty(ops.linear_stage_bytes(M, N, K, prec) + 64, dtype=torch.uint8, device=dev)
+    os.environ["ADX_GEMM_DMA_ANY"] = "1"
+    try:
+        y0 = ops.linear(x, w, b, _lib.ACT_GELU_TANH, prec, workspace=ws)
+    finally:
+        os.environ.pop("ADX_GEMM_DMA_ANY", None)
+    xp = ops.stage_planes(x, prec)
+    wp = ops.block_weight(ops.prepare_weight(w, prec), N, K, prec)
+    y1 = ops.linear_planes(xp, wp, b, M, N, K, _lib.ACT_GELU_TANH, prec)
+    assert torch.equal(y0, y1)
+    xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if prec == "bf16" else (x.double(), w.double())
+    ref = torch.nn.functional.gelu(xr[:512] @ wr.T + b.double(), approximate="tanh").float()
+    assert rel_err(y1[:512].cpu(), ref.cpu()) < 2e-5
+    with pytest.raises(_lib.AdxError):
+        ops.linear_planes(xp, wp, b, 128, N, K, precision=prec)          # too few rows for the kernel
+    with pytest.raises(_lib.AdxError):
+        ops.linear_planes(xp[8:], wp, b, M - 1, N, K, precision=prec)    # planes not 16-byte aligned
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("M,N,K", [(262144 + 77, 776, 256), (131072, 70, 128), (140000, 96, 64)])
 def test_op_linear_row_stationary(dev, M, N, K, prec):
     """Short K and many rows take the row-stationary kernel (X fragments in registers, W streamed through LDS): ragged M and
