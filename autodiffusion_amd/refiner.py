@@ -394,14 +394,18 @@ class DiffusionAugmentation(nn.Module):
         label = _lib.f32c(trajectory_label).reshape(B, n_chunks, fs, -1)
         prior = _lib.f32c(trajectory_prior).reshape(B, n_chunks, fs, -1)
         transition = self.init_x[None].expand(B, *self.init_x.shape).contiguous()
-        self.diffusion.train()
+        was_training = self.diffusion.training
+        self.diffusion.train()                # the wrapper's forward() switches on the mode: loss when training, sample otherwise
         losses, preds = [], []
-        for c in range(n_chunks):
-            l, prediction = self.diffusion(label[:, c].contiguous(), transition, prior[:, c].contiguous(), maps_info,
-                                           t=None if t is None else t[c], noise=None if noise is None else noise[c])
-            transition = prediction
-            losses.append(l.reshape(()))
-            preds.append(prediction)
+        try:
+            for c in range(n_chunks):
+                l, prediction = self.diffusion(label[:, c].contiguous(), transition, prior[:, c].contiguous(), maps_info,
+                                               t=None if t is None else t[c], noise=None if noise is None else noise[c])
+                transition = prediction
+                losses.append(l.reshape(()))
+                preds.append(prediction)
+        finally:
+            self.diffusion.train(was_training)
         final_predict = torch.stack(preds, dim=1).reshape(B, S, -1)
         loss = torch.stack(losses)
         return LTMOutput(loss=loss.mean(), loss_items=loss, logits=final_predict, pred_dict={"traj_logits": final_predict},
