@@ -151,6 +151,8 @@ struct EncRowsArgs {
     const float* img_f32 = nullptr; const unsigned short* img_bf = nullptr;   // filled by the launcher
     const float* vecs = nullptr;                     // [416] bo, gamma2, beta2, b2, gamma1', beta1', b1(128), bkv(64), bq(32)
     float* kv = nullptr; int64_t ldkv = 0;           // K at kv[row*ldkv + 0..31], V at +32..63
+    float4* gpk = nullptr;                           // when set: NO K/V projection; the layer-1 LayerNorm rows are stored instead, in
+                                                     // lane order gpk[(tile * 4 + g) * 64 + lane] (128 B per row, enc_rows_g_bytes), for attention_g
     float* x1 = nullptr;                             // [B*L][32] layer-1 residual input, rows r < n_keep only
     float* q1 = nullptr; int64_t ldq1 = 0;           // layer-1 queries, rows r < n_keep only
     int B = 0, L = 0, n_keep = 0;
@@ -162,6 +164,23 @@ hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W
 size_t enc_rows_packed_bytes(int B, int L);
 hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream);      // once per chunk: x0/q/state -> packed
 hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);  // once per step
+size_t enc_rows_g_bytes(int B, int L);
+
+// Last encoder layer's attention of the n_keep visible rows of every item (n_keep * 8 heads <= 96) over ALL L rows of the item,
+// straight from the LayerNorm rows that enc_rows stored (gpk): keys and values are projected per 32-row tile on the matrix
+// cores and never exist in memory.  One workgroup of two wavefronts per item.  O[b * o_batch_stride + i * ldo + c].
+struct AttnGArgs {
+    const float4* gpk = nullptr;
+    const void* image = nullptr;                     // the enc_rows weight image (its K | V projection tiles)
+    const float* vecs = nullptr;                     // the enc_rows vectors (the V bias)
+    const float* wk = nullptr;                       // [32][32] fp32 K rows of the layer's in_proj_weight
+    const float* q1 = nullptr; int64_t ldq1 = 0;     // layer-1 query of row (b * L + i) at q1[(b * L + i) * ldq1]
+    float* O = nullptr; int64_t ldo = 0, o_batch_stride = 0;
+    int B = 0, L = 0, n_keep = 0;
+    float scale = 1.f;
+};
+bool attention_g_ok(int n_keep);
+hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream);
 
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
 hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);

@@ -54,6 +54,7 @@ struct EngineA final : adx_engine {
     bool fast4 = false;     // head_dim 4, 8 heads: the shapes the few-query / merge kernels are written for
     // elide level 3: the per-row pipeline between the two encoder attentions runs as one fused kernel
     bool fused = false;
+    bool attn_g = false;       // fused path: the last encoder attention reads the stored LayerNorm rows (no K | V in memory)
     void* rows_image = nullptr;
     float* rows_vecs = nullptr;
     // fused tail (rest of the last encoder layer + decoder + head + scheduler update in one launch)
@@ -98,6 +99,10 @@ struct EngineA final : adx_engine {
         fast4 = (H == 8 && d == 32);
         if (cfg.elide >= 2 && !fast4) cfg.elide = 1;
         fused = cfg.elide >= 3 && n_enc == 2;
+        {
+            const char* no_g = getenv("ADX_ATTN_G");              // fallback switch: 0 = few-query attention over stored K | V
+            attn_g = fused && fast4 && attention_g_ok(T + 1) && !(no_g && no_g[0] == '0');
+        }
         tail_ok = fused && T + 1 <= 12 && Cin == Cout && Cin <= 64 && (Cin % 4) == 0 && n_dec <= 4;
         const char* whole = getenv("ADX_CHUNK_CACHE_WHOLE");   // tuning knob: rebuild the whole layer-0 cache per chunk
         split_cache = fused && fast4 && cfg.map_cond && nmaps > 0 && 2 * NP <= 64 && !(whole && whole[0] == '1');
@@ -422,6 +427,7 @@ struct EngineA final : adx_engine {
         r.key0 = tqkv0 + (int64_t)step * 3 * d + d;
         r.image = rows_image; r.vecs = rows_vecs;
         r.kv = KV1; r.ldkv = 2 * d; r.x1 = par ? XB : XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
+        if (attn_g) r.gpk = reinterpret_cast<float4*>(KV1);       // the LayerNorm rows (128 B per row) take the place of K | V (256 B)
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
         return r;
     }
@@ -463,6 +469,23 @@ struct EngineA final : adx_engine {
 
     // ---------------------------------------------------------------------------------- the network
     // last encoder layer on the fused path: queries of the T+1 visible rows (in QKV) against the compact K | V rows
+    // last encoder layer's attention on the fused path: from the stored LayerNorm rows when the visible rows fit the
+    // matrix-core form (keys and values never reach memory), else few-query attention over the stored K | V
+    int last_attention(int B, int par, hipStream_t s) {
+        if (attn_g) {
+            AttnGArgs g;
+            g.gpk = reinterpret_cast<const float4*>(KV1); g.image = rows_image; g.vecs = rows_vecs;
+            g.wk = P("encoder.layers.1.self_attn.in_proj_weight") + (int64_t)d * d;
+            g.q1 = QKV; g.ldq1 = 3 * d;
+            g.O = par ? ATTb : ATT; g.ldo = d; g.o_batch_stride = (int64_t)L * d;
+            g.B = B; g.L = L; g.n_keep = T + 1; g.scale = 1.0f / sqrtf((float)(d / H));
+            ADX_HIP(attention_g(g, cfg.precision, s));
+        } else {
+            ADX_HIP(attention_few_queries(fused_attn_args(B, par), s));
+        }
+        return ADX_OK;
+    }
+
     AttentionArgs fused_attn_args(int B, int par = 0) const {
         AttentionArgs at = enc_attn_args(B, T + 1);
         if (par) at.O = ATTb;
@@ -510,7 +533,7 @@ struct EngineA final : adx_engine {
             ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s));
             prof_end(s);
             prof_begin(2, s);
-            ADX_HIP(attention_few_queries(fused_attn_args(B), s));
+            ADX_TRY(last_attention(B, 0, s));
             prof_end(s);
             if ((tail_ok || tail_mfma_ok) && io.x_next && stepped) {
                 prof_begin(3, s);
@@ -625,7 +648,7 @@ struct EngineA final : adx_engine {
             if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
             else if (stage == 1) {
                 ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s));
-            } else if (stage == 2) ADX_HIP(attention_few_queries(fused_attn_args(B), s));
+            } else if (stage == 2) ADX_TRY(last_attention(B, 0, s));
             else if (stage == 3) {
                 if (!tail_ok && !tail_mfma_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
                 ADX_TRY(launch_tail(B, XS0, nullptr, steps_dev, XS1, MOUT, s));
@@ -705,7 +728,7 @@ struct EngineA final : adx_engine {
                 }
                 if (k >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
                 ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s));
-                ADX_HIP(attention_few_queries(fused_attn_args(B, par), s));
+                ADX_TRY(last_attention(B, par, s));
                 ADX_HIP(hipEventRecord(ev_enc[par], s));
                 ADX_HIP(hipStreamWaitEvent(side_stream, ev_enc[par], 0));
                 ADX_TRY(launch_tail(B, xc, z, steps_dev + k, xn, MOUT, side_stream, par));

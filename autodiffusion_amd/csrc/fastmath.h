@@ -22,5 +22,10 @@ __device__ __forceinline__ float xor32_add(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float xor32_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 }  // namespace adx

@@ -24,6 +24,7 @@
 #include "fastmath.h"
 
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace adx {
@@ -272,7 +273,9 @@ __device__ __forceinline__ void land_row(RowIn& in) {
 
 // WAVES = resident wavefronts per SIMD the register budget is set for; a workgroup has 4 waves (WAVES <= 3, three
 // workgroups per CU) or 8 waves (WAVES = 4, two workgroups per CU), so that the LDS copies of the weight image fit.
-template <int PREC, int WAVES>
+// GOUT: the kernel ends at the layer-1 LayerNorm and stores those rows (lane order, one float4 per lane and register group:
+// four stores of 1 KB of contiguous memory per tile) for attention_g instead of projecting and storing K | V.
+template <int PREC, int WAVES, bool GOUT>
 __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
     constexpr int NT = WAVES == 4 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -411,18 +414,251 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         }
         // Lanes past the last row hold a copy of it (the packed tile repeats it) and store the same values to the same
         // place: the stores are unconditional, so exactly eight vector-memory operations follow the loads of the next tile.
+        if constexpr (GOUT) {
+            float4* gp = a.gpk + (tile0 >> 5) * (4 * 64) + lane;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const f32x16 kv = mm<PREC>(img, tile_base(3) + nt, gn, zero16(), lane);
-            float* op = a.kv + row * a.ldkv + 32 * nt;
+            for (int g = 0; g < 4; ++g) gp[64 * g] = make_float4(gn[4 * g], gn[4 * g + 1], gn[4 * g + 2], gn[4 * g + 3]);
+        } else {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 b = *reinterpret_cast<const float4*>(bkv + 32 * nt + 8 * g + 4 * h);
-                *reinterpret_cast<float4*>(op + 8 * g + 4 * h) =
-                    make_float4(kv[4 * g] + b.x, kv[4 * g + 1] + b.y, kv[4 * g + 2] + b.z, kv[4 * g + 3] + b.w);
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x16 kv = mm<PREC>(img, tile_base(3) + nt, gn, zero16(), lane);
+                float* op = a.kv + row * a.ldkv + 32 * nt;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b = *reinterpret_cast<const float4*>(bkv + 32 * nt + 8 * g + 4 * h);
+                    *reinterpret_cast<float4*>(op + 8 * g + 4 * h) =
+                        make_float4(kv[4 * g] + b.x, kv[4 * g + 1] + b.y, kv[4 * g + 2] + b.z, kv[4 * g + 3] + b.w);
+                }
             }
         }
         land_row(in);
+    }
+}
+
+// ---- last-layer attention of the few visible rows, straight from the LayerNorm rows -----------------------------------
+// An MFMA operand with "outer index on the lane, k on the registers" in the k order of feat(): exactly what an accumulator
+// holds, so every product below feeds the next one without moving data between lanes.  mma(A, B, acc) returns acc +
+// (lane <-> B's outer index, register <-> A's outer index).
+template <int PREC> struct Opnd;
+template <> struct Opnd<PREC_F32> { f32x16 v; };
+template <> struct Opnd<PREC_BF16> { bf16x8 h[2]; };
+template <> struct Opnd<PREC_BF16X3> { bf16x8 h[2], l[2]; };
+
+template <int PREC>
+__device__ __forceinline__ Opnd<PREC> to_opnd(const f32x16& v) {
+    Opnd<PREC> o;
+    if constexpr (PREC == PREC_F32) {
+        o.v = v;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = v[8 * s + j];
+                const __bf16 hi = (__bf16)x;
+                o.h[s][j] = hi;
+                if constexpr (PREC == PREC_BF16X3) o.l[s][j] = (__bf16)(x - (float)hi);
+            }
+    }
+    return o;
+}
+
+template <int PREC>
+__device__ __forceinline__ Opnd<PREC> weight_opnd(const float* img_f32, const unsigned short* img_bf, int tile, int lane) {
+    Opnd<PREC> o;
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) o.v[reg] = img_f32[(tile * 16 + reg) * 64 + lane];
+    } else {
+        const unsigned short* whi = img_bf + (tile * 2 * 64 + lane) * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            o.h[s] = *reinterpret_cast<const bf16x8*>(whi + s * 64 * 8);
+            if constexpr (PREC == PREC_BF16X3) o.l[s] = *reinterpret_cast<const bf16x8*>(whi + NFRAG_BF * 64 * 8 + s * 64 * 8);
+        }
+    }
+    return o;
+}
+
+template <int PREC>
+__device__ __forceinline__ f32x16 mma(const Opnd<PREC>& A, const Opnd<PREC>& B, f32x16 acc) {
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A.v[reg], B.v[reg], acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (PREC == PREC_BF16X3) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[s], B.l[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.l[s], B.h[s], acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.h[s], B.h[s], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+constexpr int AG_COLS = 96;            // (visible row, head) pairs: three 32-wide column blocks
+constexpr float AG_NEG = -1.0e30f;
+
+// One workgroup (two wavefronts) per item; the wavefronts take alternate 32-row groups of the item's rows and merge at the end.
+// Per group, with g the stored LayerNorm rows (lane <-> row):
+//     V   = g Wv^T        (lane <-> feature, registers <-> key)
+//     S^T = g Qt^T        (lane <-> column (row i, head), registers <-> key), Qt = Qb Wk: Qb holds the query of head hd on that
+//                          head's four features and zero elsewhere, so S is the per-head dot product of the query with Wk g;
+//                          the K bias shifts all scores of a query alike and is dropped
+//     O^T += V^T P^T      (lane <-> column, registers <-> feature), P = 2^(S - running max): the online softmax keeps its
+//                          maximum, sum and rescale factor per LANE, because a column lives on a lane in S^T and in O^T alike.
+// Only the four features of a column's own head are meaningful in O^T; they are picked at the end.
+template <int PREC, int ABL = 0>      // ABL: measurement aid (results are wrong): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights
+__global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
+    __shared__ float mrg[(6 + 48) * 64];
+    __shared__ Opnd<PREC> qsh[3][64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h2 = lane >> 5;
+    const Opnd<PREC> wv = weight_opnd<PREC>(img_f32, img_bf, tile_base(3) + 1, lane);
+    const float qs = a.scale * LOG2E_F;
+    const int64_t r0 = (int64_t)b * a.L, r1 = r0 + a.L;
+    // The query operand is the same for both wavefronts and every group: built once, kept in LDS (48 registers otherwise).
+    // The K projection is folded into it: q . (Wk g) = (Wk^T q) . g, so Qt^T = Wk^T Qb^T (lane <-> column, registers <->
+    // feature of g) is computed here and no group projects its keys.
+    if (wave == 0) {
+        f32x16 wt;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) wt[reg] = a.wk[feat(reg, h2) * D + n];       // Wk^T: lane <-> input feature, registers <-> output feature
+        const Opnd<PREC> wkt = to_opnd<PREC>(wt);
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const int col = 32 * nb + n, i = col >> 3, hd = col & 7;
+            f32x16 f = zero16();
+            if (i < a.n_keep && (hd & 1) == h2) {
+                const float4 q = *reinterpret_cast<const float4*>(a.q1 + (r0 + i) * a.ldq1 + 4 * hd);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (g == (hd >> 1)) { f[4 * g] = q.x * qs; f[4 * g + 1] = q.y * qs; f[4 * g + 2] = q.z * qs; f[4 * g + 3] = q.w * qs; }
+            }
+            qsh[nb][lane] = to_opnd<PREC>(mma<PREC>(wkt, to_opnd<PREC>(f), zero16()));
+        }
+    }
+    __syncthreads();
+    float m[3] = {AG_NEG, AG_NEG, AG_NEG}, l[3] = {0.f, 0.f, 0.f};
+    f32x16 o[3] = {zero16(), zero16(), zero16()};
+    // Keys are walked in groups of 32 rows counted from the ITEM's first row (not in the global tiles enc_rows stored them
+    // in), so that the order of the online softmax -- and with it every bit of the result -- does not depend on where in
+    // the batch the item sits.  Lane (c, h2) of group t reads row r0 + 32 t + c: two contiguous runs of the lane-ordered store.
+    const int n_groups = (a.L + 31) >> 5;
+    int t = wave;
+    float4 gv[4];
+    auto fetch = [&](int grp) {
+        const int64_t row = min(r0 + 32 * (int64_t)min(grp, n_groups - 1) + n, r1 - 1);
+        const float4* gp = a.gpk + (row >> 5) * (4 * 64) + h2 * 32 + (row & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = gp[64 * g];
+    };
+    fetch(t);
+    for (; t < n_groups; t += 2) {
+        f32x16 g16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { g16[4 * g] = gv[g].x; g16[4 * g + 1] = gv[g].y; g16[4 * g + 2] = gv[g].z; g16[4 * g + 3] = gv[g].w; }
+        fetch(t + 2);                                                   // next group (clamped: the last iteration re-reads and drops it)
+        const Opnd<PREC> gop = to_opnd<PREC>(g16);
+        // One group, as straight-line code (the masked form of the item's last group is a second copy): a wavefront issues
+        // in order, so vector work hides under matrix work only where the two alternate in the instruction stream.
+        auto group = [&](auto partial_c) {
+            constexpr bool PARTIAL = decltype(partial_c)::value;
+            // online softmax of one column block; returns the weights as an operand
+            auto soft = [&](int nb, f32x16 sc) {
+                if constexpr (PARTIAL) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (32 * t + feat(reg, h2) >= a.L) sc[reg] = AG_NEG;
+                }
+                float mx = sc[0];
+#pragma unroll
+                for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, sc[reg]);
+                mx = xor32_max(mx);
+                const float mn = fmaxf(m[nb], mx);
+                const float fac = exp2_fast(m[nb] - mn);
+                m[nb] = mn;
+                float sum = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) { sc[reg] = (ABL & 1) ? sc[reg] - mn : exp2_fast(sc[reg] - mn); sum += sc[reg]; }
+                l[nb] = fmaf(l[nb], fac, sum);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) o[nb][reg] *= fac;
+                if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
+                else return to_opnd<PREC>(sc);
+            };
+            const f32x16 s0 = (ABL & 4) ? g16 : mma<PREC>(gop, qsh[0][lane], zero16());
+            __builtin_amdgcn_sched_barrier(0);
+            // the other products of these rows (18 matrix instructions), with block 0's vector work between them
+            const f32x16 s1 = (ABL & 4) ? g16 : mma<PREC>(gop, qsh[1][lane], zero16());
+            const f32x16 vv = mma<PREC>(gop, wv, zero16());
+            const f32x16 s2 = (ABL & 4) ? g16 : mma<PREC>(gop, qsh[2][lane], zero16());
+            const Opnd<PREC> p0 = soft(0, s0);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight vector instructions
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const Opnd<PREC> vop = to_opnd<PREC>(vv);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 2) != 0) o[0][0] += (float)p0.h[0][0] + (float)vop.h[0][1]; else o[0] = mma<PREC>(vop, p0, o[0]);
+            const Opnd<PREC> p1 = soft(1, s1);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 2) != 0) o[1][0] += (float)p1.h[0][0] + (float)vop.h[0][1]; else o[1] = mma<PREC>(vop, p1, o[1]);
+            const Opnd<PREC> p2 = soft(2, s2);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((ABL & 2) != 0) o[2][0] += (float)p2.h[0][0] + (float)vop.h[0][1]; else o[2] = mma<PREC>(vop, p2, o[2]);
+        };
+        if (32 * t + 32 > a.L) group(std::true_type{});          // wave-uniform: the item's last group
+        else group(std::false_type{});
+    }
+    // ---- merge the two wavefronts, normalise, add the V bias, store the four features of each column's head
+    if (wave == 1) {
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            mrg[nb * 64 + lane] = m[nb];
+            mrg[(3 + nb) * 64 + lane] = l[nb];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) mrg[(6 + nb * 16 + reg) * 64 + lane] = o[nb][reg];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float* bv = a.vecs + 320 + 32;
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+            const float m1 = mrg[nb * 64 + lane], l1 = mrg[(3 + nb) * 64 + lane];
+            const float mn = fmaxf(m[nb], m1);
+            const float f0 = exp2_fast(m[nb] - mn), f1 = exp2_fast(m1 - mn);
+            const float inv = rcp_fast(xor32_add(fmaf(l[nb], f0, l1 * f1)));
+            const int col = 32 * nb + n, i = col >> 3, hd = col & 7;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (g == (hd >> 1)) {
+                    r.x = fmaf(o[nb][4 * g], f0, mrg[(6 + nb * 16 + 4 * g) * 64 + lane] * f1);
+                    r.y = fmaf(o[nb][4 * g + 1], f0, mrg[(6 + nb * 16 + 4 * g + 1) * 64 + lane] * f1);
+                    r.z = fmaf(o[nb][4 * g + 2], f0, mrg[(6 + nb * 16 + 4 * g + 2) * 64 + lane] * f1);
+                    r.w = fmaf(o[nb][4 * g + 3], f0, mrg[(6 + nb * 16 + 4 * g + 3) * 64 + lane] * f1);
+                }
+            if (i < a.n_keep && (hd & 1) == h2) {
+                const float4 bb = *reinterpret_cast<const float4*>(bv + 4 * hd);
+                *reinterpret_cast<float4*>(a.O + (int64_t)b * a.o_batch_stride + (int64_t)i * a.ldo + 4 * hd) =
+                    make_float4(fmaf(r.x, inv, bb.x), fmaf(r.y, inv, bb.y), fmaf(r.z, inv, bb.z), fmaf(r.w, inv, bb.w));
+            }
+        }
     }
 }
 
@@ -461,16 +697,51 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     int blocks = (int)((tiles + wpb - 1) / wpb);
     const int cap = 256 * (waves == 3 ? 3 : 2);        // resident workgroups; waves stride over the remaining tiles
     if (blocks > cap) blocks = cap;
-#define ADX_LAUNCH_ROWS(P)                                                                                          \
-    do {                                                                                                            \
-        if (waves == 4) hipLaunchKernelGGL((enc_rows_kernel<P, 4>), dim3(blocks), dim3(512), smem, stream, a);      \
-        else if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3>), dim3(blocks), dim3(256), smem, stream, a); \
-        else hipLaunchKernelGGL((enc_rows_kernel<P, 2>), dim3(blocks), dim3(256), smem, stream, a);                 \
+#define ADX_LAUNCH_ROWS2(P, G)                                                                                          \
+    do {                                                                                                               \
+        if (waves == 4) hipLaunchKernelGGL((enc_rows_kernel<P, 4, G>), dim3(blocks), dim3(512), smem, stream, a);      \
+        else if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3, G>), dim3(blocks), dim3(256), smem, stream, a); \
+        else hipLaunchKernelGGL((enc_rows_kernel<P, 2, G>), dim3(blocks), dim3(256), smem, stream, a);                 \
     } while (0)
+#define ADX_LAUNCH_ROWS(P)                                       \
+    do {                                                         \
+        if (a.gpk) ADX_LAUNCH_ROWS2(P, true);                    \
+        else ADX_LAUNCH_ROWS2(P, false);                         \
+    } while (0)
+    if (!a.gpk && !a.kv) return hipErrorInvalidValue;
     if (prec == PREC_F32) ADX_LAUNCH_ROWS(PREC_F32);
     else if (prec == PREC_BF16) ADX_LAUNCH_ROWS(PREC_BF16);
     else ADX_LAUNCH_ROWS(PREC_BF16X3);
 #undef ADX_LAUNCH_ROWS
+#undef ADX_LAUNCH_ROWS2
+    return hipGetLastError();
+}
+
+size_t enc_rows_g_bytes(int B, int L) { return (size_t)(((int64_t)B * L + 31) / 32) * 4 * 64 * sizeof(float4); }
+
+bool attention_g_ok(int n_keep) { return n_keep >= 1 && n_keep * NH <= AG_COLS; }
+
+hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream) {
+    if (a.B <= 0 || a.L <= 0 || !attention_g_ok(a.n_keep) || a.n_keep > a.L || !a.gpk || !a.image || !a.vecs || !a.wk || !a.q1 || !a.O ||
+        (a.ldq1 & 3) != 0 || (a.ldo & 3) != 0 || (a.o_batch_stride & 3) != 0 || (int64_t)a.B * a.L >= (int64_t)1 << 31)
+        return hipErrorInvalidValue;
+    const float* img_f32 = reinterpret_cast<const float*>(a.image);
+    const unsigned short* img_bf = reinterpret_cast<const unsigned short*>(img_f32 + IMG_F32_FLOATS);
+    if (prec == PREC_F32) hipLaunchKernelGGL(attn_g_kernel<PREC_F32>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+    else if (prec == PREC_BF16) hipLaunchKernelGGL(attn_g_kernel<PREC_BF16>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+    else {
+        const char* abl_env = getenv("ADX_ATTN_G_ABLATE");      // measurement aid, read per call
+        switch (abl_env ? atoi(abl_env) : 0) {
+            case 1: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 1>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 2: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 2>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 4: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 4>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 6: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 6>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 8: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 8>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 9: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 9>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 15: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 15>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            default: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        }
+    }
     return hipGetLastError();
 }
 

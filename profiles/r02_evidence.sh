@@ -25,9 +25,9 @@ if [ $part = all ] || [ $part = pmcref ]; then
     rm -f $O/pmc_refiner_b1024.txt
     echo "# rocprofv3 --pmc passes over profiles/stage_times.py bf16x3 1024 (B=1024: 828416 conditioning rows), per-launch averages" > $O/pmc_refiner_b1024.txt
     echo "# HBM bytes = TCC_EA0_RDREQ x 128 B (= FETCH_SIZE KB doubled, the gfx950 correction) + TCC_EA0_WRREQ x 64 B" >> $O/pmc_refiner_b1024.txt
-    pmc pmc_refiner_b1024 "TCC_EA0_RDREQ_sum FETCH_SIZE" "enc_rows attn_fewq3 tail_mfma" python3 profiles/stage_times.py bf16x3 1024
-    pmc pmc_refiner_b1024 "TCC_EA0_WRREQ_sum WRITE_SIZE" "enc_rows attn_fewq3 tail_mfma" python3 profiles/stage_times.py bf16x3 1024
-    pmc pmc_refiner_b1024 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "enc_rows attn_fewq3 tail_mfma" python3 profiles/stage_times.py bf16x3 1024
+    pmc pmc_refiner_b1024 "TCC_EA0_RDREQ_sum FETCH_SIZE" "enc_rows attn_g tail_mfma" python3 profiles/stage_times.py bf16x3 1024
+    pmc pmc_refiner_b1024 "TCC_EA0_WRREQ_sum WRITE_SIZE" "enc_rows attn_g tail_mfma" python3 profiles/stage_times.py bf16x3 1024
+    pmc pmc_refiner_b1024 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "enc_rows attn_g tail_mfma" python3 profiles/stage_times.py bf16x3 1024
     cat $O/pmc_refiner_b1024.txt
 fi
 if [ $part = all ] || [ $part = gemm ]; then
