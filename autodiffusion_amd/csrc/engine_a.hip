@@ -73,6 +73,7 @@ struct EngineA final : adx_engine {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
     bool overlap_ok = false;
+    int overlap_max_b = 1536;
 
     ~EngineA() override {
         if (tqkv0) (void)hipFree(tqkv0);
@@ -672,6 +673,8 @@ struct EngineA final : adx_engine {
             }
             const char* no = getenv("ADX_NO_OVERLAP");                   // fallback switch: every kernel of a step on one stream
             overlap_ok = !(no && no[0] == '1');
+            const char* mb = getenv("ADX_OVERLAP_MAX_B");                // tuning knob: largest batch whose tail runs on the second stream
+            if (mb) overlap_max_b = atoi(mb);
         }
         return ADX_OK;
     }
@@ -712,7 +715,7 @@ struct EngineA final : adx_engine {
         // Measured (frame_stack 10, one MI355X, trajectories/s with / without): B=512 9810 / 8040, B=1024 11100 / 9130, B=2048 10830 / 10950,
         // B=4096 10940 / 11530 -- below ~2k scenarios the one-wavefront-per-scenario tail leaves the chip mostly idle and hides
         // under the encoder kernels; above, both fill the chip and only disturb each other.
-        const bool overlap = cached && fused && (tail_ok || tail_mfma_ok) && overlap_ok && !profiling && side_stream && B <= 1536;
+        const bool overlap = cached && fused && (tail_ok || tail_mfma_ok) && overlap_ok && !profiling && side_stream && B <= overlap_max_b;
         if (overlap) {
             // stream s: encoder rows + last-layer attention of step k (buffers of parity k & 1);
             // side stream: tail of step k, after its encoder kernels and (stream order) after the tail of step k - 1.

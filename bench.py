@@ -74,16 +74,22 @@ def time_kernel(fn, iters=20):
 # HBM bytes of one launch of the encoder row kernel at B = 1024 from the L2 fabric-request counters (separate rocprofv3
 # --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
 # the per-row figure scales with B.  Source: profiles/r02_pmc_refiner.txt.
-ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (2698418.7 * 128 + 3414617.1 * 64) / (1024 * L_COND)
-ENC_ROWS_ALGO_BYTES_PER_ROW = 416 + 256      # read x0 (128) + layer-0 query (128) + normalised softmax state (160); write layer-1 K, V (256)
+ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (2699403.8 * 128 + 1702047.8 * 64) / (1024 * L_COND)
+ENC_ROWS_READ_BYTES_PER_ROW = 416            # x0 (128) + layer-0 query (128) + normalised softmax state (160)
+
+
+def enc_rows_write_bytes_per_row(fs):
+    """The layer-1 LayerNorm row (128 B) while the visible rows fit the matrix-core attention ((fs + 1) x 8 heads <= 96);
+    layer-1 K | V (256 B) for longer chunks, whose last attention reads stored keys and values."""
+    return 128 if (fs + 1) * N_HEAD <= 96 else 256
 
 
 def roofline(da, B, step):
     """Dominant kernel of a denoiser call: the fused encoder row pipeline (enc_rows_kernel), one launch per call.
 
-    It streams every conditioning row once -- 672 algorithmic bytes per row, B * 809 rows per launch -- and does
-    22.5 kflop per row on the matrix cores, so HBM bandwidth is the roof that binds (73 us at 8 TB/s against 7.5 us
-    at the dense bf16 MFMA peak).  Its launches are timed inside one more pass of the workload: the engine brackets
+    It streams every conditioning row once -- 544 algorithmic bytes per row (416 read, 128 written), B * 809 rows per
+    launch -- and does 18.4 kflop per row on the matrix cores, so HBM bandwidth is the roof that binds (56 us at 8 TB/s
+    against 6 us at the dense bf16 MFMA peak, B = 1024).  Its launches are timed inside one more pass of the workload: the engine brackets
     every marked launch with events on the launch stream (no graph capture during that pass).  ``stages_us`` lists the
     other kernels of a call from the same pass.
     """
@@ -102,11 +108,12 @@ def roofline(da, B, step):
     finally:
         eng.profile(False)
     rows = B * L_COND
-    algo = float(ENC_ROWS_ALGO_BYTES_PER_ROW * rows)
+    wr = enc_rows_write_bytes_per_row(FS)
+    algo = float((ENC_ROWS_READ_BYTES_PER_ROW + wr) * rows)
     achieved = algo / t["enc_rows"] / 1e9
-    return {"kernel": "enc_rows_kernel (encoder layer 0 tail + layer 1 K/V over all conditioning rows)", "bound": "hbm",
+    return {"kernel": "enc_rows_kernel (encoder layer 0 after its attention + layer 1 LayerNorm over all conditioning rows)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows), "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
+            "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows) if wr == 128 and FS == 10 else None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
             "launches_timed": launches, "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()}}
 
 
