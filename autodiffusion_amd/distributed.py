@@ -30,8 +30,9 @@ class RowGatherer:
     gather (trainer.py:665-692) -- and ``gather`` then compacts the rows in place, again without allocating.
     """
 
-    def __init__(self, total: int, row_shape: Tuple[int, ...], device, dtype=torch.float32):
+    def __init__(self, total: int, row_shape: Tuple[int, ...], device, dtype=torch.float32, always_collective: bool = False):
         self.total = int(total)
+        self.always_collective = bool(always_collective) and dist.is_initialized()     # run the collective even in a group of one
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.spans = [shard_range(self.total, r, self.world) for r in range(self.world)]
@@ -47,7 +48,7 @@ class RowGatherer:
 
     def gather(self, local: torch.Tensor) -> torch.Tensor:
         """-> (total, ...) rows of all ranks, a view of the preallocated buffer (valid until the next call)."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return local
         if local.shape[0] != self.rows:
             raise ValueError(f"rank {self.rank} owns {self.rows} rows, got {local.shape[0]}")

@@ -324,7 +324,10 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ADX_BENCH_DIST=1: join the process group even as a single rank, so that a one-GPU box exercises RCCL's set-up, barrier,
+    # all-reduce and all-gather exactly as an N-rank run does
+    use_dist = world > 1 or (os.environ.get("ADX_BENCH_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
@@ -346,15 +349,17 @@ def main():
         """K timed generate() passes (+ gather) over B scenarios per rank; returns (seconds, step function, gathered rows)."""
         maps, prior, noise = make_inputs(B, rank * B, dev, n_noise)
         out = torch.empty(B, 80, 4, device=dev)
-        gatherer = RowGatherer(B * world, (80, 4), dev)
+        gatherer = RowGatherer(B * world, (80, 4), dev, always_collective=use_dist)
+
+        def sample():
+            return da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)["traj_logits"]
 
         def step():
-            da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
-            return gatherer.gather(out)               # enqueued behind the sampling graph on the same stream
+            return gatherer.gather(sample())          # enqueued behind the sampling graph on the same stream
 
         def fence():
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -366,16 +371,16 @@ def main():
             gathered = step()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         assert gathered.shape[0] == B * world and bool(torch.isfinite(gathered).all())
-        return dt, step
+        return dt, sample
 
     B = args.batch or 1024
     total = B * world
-    dt, step = measure(B, args.steps, args.warmup)
+    dt, sample = measure(B, args.steps, args.warmup)
 
     if rank == 0:
         line = {
@@ -391,14 +396,14 @@ def main():
                                      "bf16": "bf16 MFMA operands, f32 accumulate; trajectory path and scheduler f32",
                                      "fp32": "f32 MFMA"}[args.precision]},
         }
-        if world == 1 and FS == 10:                              # the fused kernels the roofline entry describes need T + 1 <= 16
-            line["roofline"] = roofline(da, B, step)
+        if FS == 10:                                             # the fused kernels the roofline entry describes need T + 1 <= 16
+            line["roofline"] = roofline(da, B, sample)           # rank 0 only: the pass runs no collective
     if world == 1 and not args.no_extras and not args.batch and FS == 10:
         B2 = 4096
-        dt2, step2 = measure(B2, 3, 1)
+        dt2, sample2 = measure(B2, 3, 1)
         knee = {"batch_per_gpu": B2, "value": round(B2 * 3 / dt2, 2), "unit": "trajectories/s", "ms_per_step": round(dt2 / 3 * 1e3, 3),
                 "note": "same workload at 4x the configured batch: every per-step kernel fills the 256 CUs"}
-        r2 = roofline(da, B2, step2)
+        r2 = roofline(da, B2, sample2)
         knee["roofline_frac"], knee["launch_us"] = r2["frac"], r2["launch_us"]
         line["knee"] = knee
         line["dit_gemm"] = dit_gemm(dev)
@@ -406,7 +411,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -544,6 +544,30 @@ def test_shard_invariance(dev):
             assert rel_err(full.cpu(), _oracle_generate(da, B, fs, N)) < GATE
 
 
+@pytest.mark.parametrize("fs", [5, 10])
+def test_last_attention_forms_agree(dev, fs):
+    """The last encoder attention has two forms on the fused path: from the stored LayerNorm rows (keys and values projected
+    per 32-row group on the matrix cores, never stored) and few-query attention over stored K | V (ADX_ATTN_G=0, what longer
+    chunks always take).  Same products in a different order: fp32 results agree to rounding, and both match the oracle;
+    ragged batch (7 items: scenarios start at every offset inside the 32-row store tiles)."""
+    from autodiffusion_amd import synth
+    B, N = 7, 10
+    noise = synth.noise(B, (80 // fs, N), (fs, 4), NSEED).to(dev)
+    prior = synth.trajectory_prior(B, ISEED).to(dev)
+    maps = synth.maps_info(B, ISEED).to(dev)
+    outs = {}
+    for form in ("1", "0"):
+        os.environ["ADX_ATTN_G"] = form
+        try:
+            da = _make_da(fs, N, "fp32", "seeded", dev)
+            outs[form] = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].cpu()
+        finally:
+            os.environ.pop("ADX_ATTN_G", None)
+    assert rel_err(outs["1"], outs["0"]) < 2e-5
+    ref = _oracle_generate(da, B, fs, N)
+    assert rel_err(outs["1"], ref) < GATE and rel_err(outs["0"], ref) < GATE
+
+
 def test_full_size_properties(dev):
     """The bench configuration at full size (4096 scenarios, DDIM 50 of 100, split-bf16 operands), through properties that
     do not need a full-size oracle: two runs are bit-identical; the first and the last rows equal what a 3-row batch of the same
