@@ -941,7 +941,8 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
             if (live) {
                 if constexpr (X3) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl[j], acc[i][j], 0, 0, 0);
+                    // measurement aid (128): two-term product, the low halves of W dropped (W effectively rounded to bf16)
+                    if constexpr (!(ABL & 128)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl[j], acc[i][j], 0, 0, 0);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh[j], acc[i][j], 0, 0, 0);
             }
@@ -1096,6 +1097,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
             case 20: kern2 = &linear_glds2_kernel<X3, 20>; break;
             case 27: kern2 = &linear_glds2_kernel<X3, 27>; break;
             case 80: kern2 = &linear_glds2_kernel<X3, 80>; break;
+            case 144: kern2 = &linear_glds2_kernel<X3, 144>; break;
             default: break;
         }
         if constexpr (!X3) {            // single-pass bf16 can walk its 6-slot ring 2 or 3 K-steps per barrier.  Measured (M=20480 N=4096 K=1024,
