@@ -151,10 +151,13 @@ struct EncRowsArgs {
     const float* img_f32 = nullptr; const unsigned short* img_bf = nullptr;   // filled by the launcher
     const float* vecs = nullptr;                     // [416] bo, gamma2, beta2, b2, gamma1', beta1', b1(128), bkv(64), bq(32)
     float* kv = nullptr; int64_t ldkv = 0;           // K at kv[row*ldkv + 0..31], V at +32..63
+    const float4* gates = nullptr;                   // when set (with gpk): this step's slice of the gate table (enc_rows_pack_gates), and
+                                                     // `packed` holds the 8-vector layout that goes with it
     float4* gpk = nullptr;                           // when set: NO K/V projection; the layer-1 LayerNorm rows are stored instead, in
                                                      // lane order gpk[(tile * 4 + g) * 64 + lane] (128 B per row, enc_rows_g_bytes), for attention_g
     float* x1 = nullptr;                             // [B*L][32] layer-1 residual input, rows r < n_keep only
-    float* q1 = nullptr; int64_t ldq1 = 0;           // layer-1 queries, rows r < n_keep only
+    float* q1 = nullptr; int64_t ldq1 = 0;           // layer-1 queries, rows r < n_keep only: row r of item b at q1[b * q1_item_stride + r * ldq1]
+    int64_t q1_item_stride = 0;                      // 0: L * ldq1 (the rows of a [B*L][ldq1] buffer)
     int B = 0, L = 0, n_keep = 0;
     float scale = 1.f;
 };
@@ -165,6 +168,11 @@ size_t enc_rows_packed_bytes(int B, int L);
 hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream);      // once per chunk: x0/q/state -> packed
 hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);  // once per step
 size_t enc_rows_g_bytes(int B, int L);
+// Gate-table form (once per chunk instead of enc_rows_pack): packed <- x0 and o / l in lane order, gates[step][tile][lane] <- the
+// fold gates of every step (tq: [n_steps][96] per-step q | k | v rows of the time token).  A step then passes
+// gates + step * (enc_rows_gates_bytes(B, L, 1) / 16) in EncRowsArgs::gates.
+size_t enc_rows_gates_bytes(int B, int L, int n_steps);
+hipError_t enc_rows_pack_gates(const EncRowsArgs& a, float4* gates, const float* tq, int n_steps, hipStream_t stream);
 
 // Last encoder layer's attention of the n_keep visible rows of every item (n_keep * 8 heads <= 96) over ALL L rows of the item,
 // straight from the LayerNorm rows that enc_rows stored (gpk): keys and values are projected per 32-row tile on the matrix
@@ -174,7 +182,8 @@ struct AttnGArgs {
     const void* image = nullptr;                     // the enc_rows weight image (its K | V projection tiles)
     const float* vecs = nullptr;                     // the enc_rows vectors (the V bias)
     const float* wk = nullptr;                       // [32][32] fp32 K rows of the layer's in_proj_weight
-    const float* q1 = nullptr; int64_t ldq1 = 0;     // layer-1 query of row (b * L + i) at q1[(b * L + i) * ldq1]
+    const float* q1 = nullptr; int64_t ldq1 = 0;     // layer-1 query of visible row i of item b at q1[b * q1_item_stride + i * ldq1]
+    int64_t q1_item_stride = 0;                      // 0: L * ldq1
     float* O = nullptr; int64_t ldo = 0, o_batch_stride = 0;
     int B = 0, L = 0, n_keep = 0;
     float scale = 1.f;

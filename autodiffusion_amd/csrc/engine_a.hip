@@ -70,8 +70,12 @@ struct EngineA final : adx_engine {
     // encoder side does not depend on x at all: the tail of step k runs on a second stream under the encoder kernels of
     // step k + 1.  Its inputs (the last encoder layer's attention output and residual rows) are double-buffered by step parity.
     float *ATTb = nullptr;                    // second buffer of ATT (XB is the second buffer of XA)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+    float *GT = nullptr;                      // [n_steps][tiles][64] float4: the fold gates of every step of the chunk (gate-table form of the row kernel)
+    bool gate_table = false;
+    float *Q1C = nullptr;                     // [2][B][T + 1][d] layer-1 queries of the visible rows, by step parity (LayerNorm-row attention)
+    hipStream_t side_stream = nullptr, att_stream = nullptr;
+    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_att[2] = {nullptr, nullptr};
+    int overlap_streams = 2;                  // 3: the last encoder attention of step k runs on a stream of its own, beside the row kernel of step k + 1
     bool overlap_ok = false;
     int overlap_max_b = 1536;
 
@@ -84,6 +88,8 @@ struct EngineA final : adx_engine {
         if (tailm_image) (void)hipFree(tailm_image);
         if (tailm_vecs) (void)hipFree(tailm_vecs);
         if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (att_stream) (void)hipStreamDestroy(att_stream);
+        for (int i = 0; i < 2; ++i) if (ev_att[i]) (void)hipEventDestroy(ev_att[i]);
         for (hipEvent_t e : ev_enc) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_tail) if (e) (void)hipEventDestroy(e);
     }
@@ -165,7 +171,17 @@ struct EngineA final : adx_engine {
             take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
             take(&ATT0, (size_t)B * std::max<size_t>(steps.size(), 1) * d);
             if (split_cache) take(&STM, BL * H * 6);
-            take(&KV1, BL * 2 * d);
+            take(&KV1, std::max<int64_t>(BL * 2 * d, 2 * (int64_t)(enc_rows_g_bytes(B, L) / sizeof(float))));      // K | V rows, or two parities of LayerNorm rows
+            take(&Q1C, 2 * (int64_t)B * (T + 1) * d);
+            {
+                // the gate table costs 32 B per row and step: used while it stays under a budget (long DDPM schedules at large
+                // batches fall back to evaluating the gates inside the row kernel)
+                const char* mb = getenv("ADX_GATE_TABLE_MAX_MB");      // tuning knob; 0 turns the table off
+                const size_t budget = (size_t)(mb ? atoll(mb) : 16384) << 20;
+                const size_t need = steps.empty() ? 0 : enc_rows_gates_bytes(B, L, (int)steps.size());
+                gate_table = attn_g && need > 0 && need <= budget;
+                if (gate_table) take(&GT, (int64_t)(need / sizeof(float)));
+            }
             take(&ATTb, BL * d);
         }
         *bytes = off;
@@ -409,7 +425,8 @@ struct EngineA final : adx_engine {
             ADX_HIP(attention(at, s));
         }
         if (fused) {
-            ADX_HIP(enc_rows_pack(rows_args(B, 0), s));
+            if (gate_table) ADX_HIP(enc_rows_pack_gates(rows_args(B, 0), reinterpret_cast<float4*>(GT), tqkv0, (int)steps.size(), s));
+            else ADX_HIP(enc_rows_pack(rows_args(B, 0), s));
             // the time token's attention for every step of the chunk in one pass over the keys
             RowsAttnArgs tr;
             tr.Q = tqkv0; tr.ldq = 3 * d; tr.q_batch_stride = 0; tr.own = 1;
@@ -420,6 +437,8 @@ struct EngineA final : adx_engine {
         return ADX_OK;
     }
 
+    float4* g_rows(int B, int par) const { return reinterpret_cast<float4*>(KV1) + (int64_t)par * (int64_t)(enc_rows_g_bytes(B, L) / sizeof(float4)); }
+
     EncRowsArgs rows_args(int B, int step, int par = 0) const {
         EncRowsArgs r;
         r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.packed = reinterpret_cast<const float4*>(PK);
@@ -428,7 +447,11 @@ struct EngineA final : adx_engine {
         r.key0 = tqkv0 + (int64_t)step * 3 * d + d;
         r.image = rows_image; r.vecs = rows_vecs;
         r.kv = KV1; r.ldkv = 2 * d; r.x1 = par ? XB : XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
-        if (attn_g) r.gpk = reinterpret_cast<float4*>(KV1);       // the LayerNorm rows (128 B per row) take the place of K | V (256 B)
+        if (attn_g) {       // the LayerNorm rows (128 B per row) take the place of K | V (256 B); they and the queries are double-buffered by step parity
+            r.gpk = g_rows(B, par);
+            if (gate_table) r.gates = reinterpret_cast<const float4*>(GT) + (int64_t)step * (int64_t)(enc_rows_gates_bytes(B, L, 1) / sizeof(float4));
+            r.q1 = Q1C + (int64_t)par * B * (T + 1) * d; r.ldq1 = d; r.q1_item_stride = (int64_t)(T + 1) * d;
+        }
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
         return r;
     }
@@ -475,9 +498,9 @@ struct EngineA final : adx_engine {
     int last_attention(int B, int par, hipStream_t s) {
         if (attn_g) {
             AttnGArgs g;
-            g.gpk = reinterpret_cast<const float4*>(KV1); g.image = rows_image; g.vecs = rows_vecs;
+            g.gpk = g_rows(B, par); g.image = rows_image; g.vecs = rows_vecs;
             g.wk = P("encoder.layers.1.self_attn.in_proj_weight") + (int64_t)d * d;
-            g.q1 = QKV; g.ldq1 = 3 * d;
+            g.q1 = Q1C + (int64_t)par * B * (T + 1) * d; g.ldq1 = d; g.q1_item_stride = (int64_t)(T + 1) * d;
             g.O = par ? ATTb : ATT; g.ldo = d; g.o_batch_stride = (int64_t)L * d;
             g.B = B; g.L = L; g.n_keep = T + 1; g.scale = 1.0f / sqrtf((float)(d / H));
             ADX_HIP(attention_g(g, cfg.precision, s));
@@ -673,6 +696,10 @@ struct EngineA final : adx_engine {
             }
             const char* no = getenv("ADX_NO_OVERLAP");                   // fallback switch: every kernel of a step on one stream
             overlap_ok = !(no && no[0] == '1');
+            ADX_HIP(hipStreamCreateWithFlags(&att_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) ADX_HIP(hipEventCreateWithFlags(&ev_att[i], hipEventDisableTiming));
+            const char* ns = getenv("ADX_OVERLAP_STREAMS");               // tuning knob: 2 = tail on a second stream, 3 = attention on a third
+            if (ns) overlap_streams = atoi(ns);
             const char* mb = getenv("ADX_OVERLAP_MAX_B");                // tuning knob: largest batch whose tail runs on the second stream
             if (mb) overlap_max_b = atoi(mb);
         }
@@ -731,9 +758,19 @@ struct EngineA final : adx_engine {
                 }
                 if (k >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
                 ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s));
-                ADX_TRY(last_attention(B, par, s));
-                ADX_HIP(hipEventRecord(ev_enc[par], s));
-                ADX_HIP(hipStreamWaitEvent(side_stream, ev_enc[par], 0));
+                if (overlap_streams >= 3 && attn_g) {
+                    // the row kernel of step k + 1 does not wait for this attention: its outputs (rows, queries, residual rows)
+                    // go to the other parity, and the buffers of this parity are free again once the tail of step k is done
+                    ADX_HIP(hipEventRecord(ev_enc[par], s));
+                    ADX_HIP(hipStreamWaitEvent(att_stream, ev_enc[par], 0));
+                    ADX_TRY(last_attention(B, par, att_stream));
+                    ADX_HIP(hipEventRecord(ev_att[par], att_stream));
+                    ADX_HIP(hipStreamWaitEvent(side_stream, ev_att[par], 0));
+                } else {
+                    ADX_TRY(last_attention(B, par, s));
+                    ADX_HIP(hipEventRecord(ev_enc[par], s));
+                    ADX_HIP(hipStreamWaitEvent(side_stream, ev_enc[par], 0));
+                }
                 ADX_TRY(launch_tail(B, xc, z, steps_dev + k, xn, MOUT, side_stream, par));
                 if (trace_x) ADX_HIP(copy2d(xc, n, 0, trace_x + k * n, n, 1, (int)n, side_stream));
                 if (trace_out) ADX_HIP(copy2d(MOUT, n, 0, trace_out + k * n, n, 1, (int)n, side_stream));

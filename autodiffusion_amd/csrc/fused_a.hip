@@ -252,6 +252,84 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, flo
     for (int v = 0; v < 5; ++v) dst[64 * (8 + v)] = make_float4(e[4 * v], e[4 * v + 1], e[4 * v + 2], e[4 * v + 3]);
 }
 
+// Gate-table form: the only step-dependent part of the fold, the gate g of each head, is tabulated per chunk for every
+// step (pack_gates_kernel), so a step reads x0 (128 B), o / l (128 B) and four gates (32 B per row: 16 B per lane) --
+// 288 B per row instead of 416 -- and evaluates no exponential or reciprocal for the fold.
+struct RowInG {
+    float4 x[4];      // x0 features 8g + 4h .. +3
+    float4 o[4];      // o / l of heads 2g + h
+    float4 gate;      // gates of heads h, 2 + h, 4 + h, 6 + h for this step
+};
+constexpr int PACK_VECS_G = 8;
+
+__device__ __forceinline__ void load_row(RowInG& in, const float4* __restrict__ p, const float4* __restrict__ gp) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) in.x[g] = p[64 * g];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) in.o[g] = p[64 * (4 + g)];
+    in.gate = *gp;
+}
+
+__device__ __forceinline__ void land_row(RowInG& in) {
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    v4* p = reinterpret_cast<v4*>(&in);
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]));
+}
+
+// One thread per (tile, lane): the step-independent inputs in lane order (x0, o / l) and, for every step of the schedule,
+// the gates of the lane's four heads: g = 1 / (1 + 2^(c - s)), c = m + log2 l of the cached state, s the scaled score of the
+// step's time-token key against the row's layer-0 query -- the very expressions of the in-kernel fold, so both forms of the
+// row kernel return the same bits.  tq: the per-step q | k | v rows of the time token ([n_steps][96], keys at +32).
+__global__ __launch_bounds__(256) void pack_gates_kernel(const EncRowsArgs a, float4* __restrict__ packed, float4* __restrict__ gates, int64_t n_tiles,
+                                                         const float* __restrict__ tq, int n_steps, float sc) {
+    constexpr int CH = 128;                                   // steps staged in LDS at a time
+    __shared__ float ks[CH * D];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n_tiles * 64;
+    const int lane = (int)(i & 63);
+    const int64_t tile = live ? i >> 6 : 0;
+    const int64_t n_rows = (int64_t)a.B * a.L;
+    const int64_t row = min(tile * 32 + (lane & 31), n_rows - 1);
+    const int h = lane >> 5;
+    float4 q[4];
+    float c[4];
+    {
+        float4* dst = packed + tile * (PACK_VECS_G * 64) + lane;
+        const float4* sp = reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24);      // 96 bytes: 4 x {m, l, o[4]}
+        float st[24];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) { const float4 t = sp[v]; st[4 * v] = t.x; st[4 * v + 1] = t.y; st[4 * v + 2] = t.z; st[4 * v + 3] = t.w; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            q[g] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * g);
+            const float inv = rcp_fast(st[6 * g + 1]);
+            c[g] = st[6 * g] + __builtin_amdgcn_logf(st[6 * g + 1]);
+            if (live) {
+                dst[64 * g] = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * g);
+                dst[64 * (4 + g)] = make_float4(st[6 * g + 2] * inv, st[6 * g + 3] * inv, st[6 * g + 4] * inv, st[6 * g + 5] * inv);
+            }
+        }
+    }
+    for (int s0 = 0; s0 < n_steps; s0 += CH) {
+        const int ns = min(CH, n_steps - s0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ns * D; e += 256) ks[e] = tq[(int64_t)(s0 + e / D) * (3 * D) + D + (e % D)] * sc;
+        __syncthreads();
+        if (live) {
+            for (int k = 0; k < ns; ++k) {
+                float gt[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 kk = *reinterpret_cast<const float4*>(ks + k * D + 8 * g + 4 * h);
+                    const float sv = fmaf(q[g].x, kk.x, fmaf(q[g].y, kk.y, fmaf(q[g].z, kk.z, q[g].w * kk.w)));
+                    gt[g] = rcp_fast(1.0f + exp2_fast(c[g] - sv));
+                }
+                gates[((int64_t)(s0 + k) * n_tiles + tile) * 64 + lane] = make_float4(gt[0], gt[1], gt[2], gt[3]);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void load_row(RowIn& in, const float4* __restrict__ p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) in.x[g] = p[64 * g];
@@ -275,7 +353,9 @@ __device__ __forceinline__ void land_row(RowIn& in) {
 // workgroups per CU) or 8 waves (WAVES = 4, two workgroups per CU), so that the LDS copies of the weight image fit.
 // GOUT: the kernel ends at the layer-1 LayerNorm and stores those rows (lane order, one float4 per lane and register group:
 // four stores of 1 KB of contiguous memory per tile) for attention_g instead of projecting and storing K | V.
-template <int PREC, int WAVES, bool GOUT>
+// ABL: measurement aid (results are wrong): 1 the FFN activation is the identity, 2 no FFN products, 4 no stores of the row output,
+// 8 every tile re-reads the wave's first tile (L2 hits instead of HBM)
+template <int PREC, int WAVES, bool GOUT, bool GATES, int ABL = 0>
 __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
     constexpr int NT = WAVES == 4 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -300,8 +380,12 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
     // projections), where few registers are live: the loads are in flight during a quarter of the tile time instead of
     // only while the wave waits for them, which is what keeps enough bytes in flight to use the HBM.
     const int64_t last_tile = (n_rows - 1) >> 5;
-    RowIn in;
-    load_row(in, a.packed + min((int64_t)wave_global, last_tile) * (PACK_VECS * 64) + lane);
+    typename std::conditional<GATES, RowInG, RowIn>::type in;
+    auto fetch_row = [&](int64_t tile) {
+        if constexpr (GATES) load_row(in, a.packed + tile * (PACK_VECS_G * 64) + lane, a.gates + tile * 64 + lane);
+        else load_row(in, a.packed + tile * (PACK_VECS * 64) + lane);
+    };
+    fetch_row(min((int64_t)wave_global, last_tile));
     land_row(in);
     for (int64_t tile0 = (int64_t)wave_global * 32; tile0 < n_rows; tile0 += (int64_t)n_waves * 32) {
         asm volatile("" ::: "memory");      // keep the per-lane bias / LayerNorm vectors in LDS: hoisting them costs ~100 registers
@@ -323,6 +407,17 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             typedef __attribute__((ext_vector_type(4))) float v4;
             v4* xp = reinterpret_cast<v4*>(in.x);
             asm volatile("" : "+v"(att), "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]));
+        } else if constexpr (GATES) {
+            const float gt[4] = {in.gate.x, in.gate.y, in.gate.z, in.gate.w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 vv = *reinterpret_cast<const float4*>(v0s + 8 * g + 4 * h);
+                const float4 o = in.o[g];
+                att[4 * g + 0] = fmaf(gt[g], vv.x - o.x, o.x);
+                att[4 * g + 1] = fmaf(gt[g], vv.y - o.y, o.y);
+                att[4 * g + 2] = fmaf(gt[g], vv.z - o.z, o.z);
+                att[4 * g + 3] = fmaf(gt[g], vv.w - o.w, o.w);
+            }
         } else {
             const float* stf = reinterpret_cast<const float*>(in.st);
 #pragma unroll
@@ -354,7 +449,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             WFrag w1 = load_w(img, tile_base(1), lane);
 #pragma unroll 1
             for (int nt = 0; nt < 4; ++nt) {
-                f32x16 f = mm_w(w1, hn, zero16());
+                f32x16 f = (ABL & 2) ? hn : mm_w(w1, hn, zero16());
                 const WFrag w2 = load_w(img, tile_base(2) + nt, lane);          // lands under the GELU
                 float4 bb[4];
 #pragma unroll
@@ -363,13 +458,13 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 b = bb[g];
-                    const f32x2 lo = gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
-                    const f32x2 hi = gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
+                    const f32x2 lo = (ABL & 1) ? f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y} : gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
+                    const f32x2 hi = (ABL & 1) ? f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w} : gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
                     f[4 * g + 0] = lo.x; f[4 * g + 1] = lo.y; f[4 * g + 2] = hi.x; f[4 * g + 3] = hi.y;
                 }
                 w1 = load_w(img, tile_base(1) + min(nt + 1, 3), lane);          // lands under the MFMAs below
                 __builtin_amdgcn_sched_barrier(0);
-                acc2 = mm_w(w2, f, acc2);
+                if constexpr ((ABL & 2) != 0) { for (int q = 0; q < 16; ++q) acc2[q] += f[q]; } else acc2 = mm_w(w2, f, acc2);
             }
         } else {
 #pragma unroll 1
@@ -394,7 +489,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         }
         // ---- next tile's inputs (clamped: a wave's last iteration re-reads the last tile and drops it)
         asm volatile("" ::: "memory");
-        load_row(in, a.packed + min((tile0 >> 5) + n_waves, last_tile) * (PACK_VECS * 64) + lane);
+        fetch_row((ABL & 8) ? min((int64_t)wave_global, last_tile) : min((tile0 >> 5) + n_waves, last_tile));
         // ---- layer 1: LayerNorm, K/V projection
         const f32x16 gn = layer_norm32(y2, g1, be1, h);
         const bool keep = live && r < a.n_keep;     // rows the decoder can see: they also need the layer-1 residual and query
@@ -402,7 +497,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             const f32x16 q1 = mm<PREC>(img, tile_base(4), gn, zero16(), lane);
             if (keep) {
                 float* xo = a.x1 + row * D;
-                float* qo = a.q1 + row * a.ldq1;
+                float* qo = a.q1 + (int64_t)((unsigned)row / (unsigned)a.L) * a.q1_item_stride + (int64_t)r * a.ldq1;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 b = *reinterpret_cast<const float4*>(bq + 8 * g + 4 * h);
@@ -416,6 +511,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         // place: the stores are unconditional, so exactly eight vector-memory operations follow the loads of the next tile.
         if constexpr (GOUT) {
             float4* gp = a.gpk + (tile0 >> 5) * (4 * 64) + lane;
+            if constexpr ((ABL & 4) != 0) { if (gn[0] == 123.456f) gp[0] = make_float4(gn[0], gn[1], gn[2], gn[3]); } else
 #pragma unroll
             for (int g = 0; g < 4; ++g) gp[64 * g] = make_float4(gn[4 * g], gn[4 * g + 1], gn[4 * g + 2], gn[4 * g + 3]);
         } else {
@@ -531,7 +627,7 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
             const int col = 32 * nb + n, i = col >> 3, hd = col & 7;
             f32x16 f = zero16();
             if (i < a.n_keep && (hd & 1) == h2) {
-                const float4 q = *reinterpret_cast<const float4*>(a.q1 + (r0 + i) * a.ldq1 + 4 * hd);
+                const float4 q = *reinterpret_cast<const float4*>(a.q1 + (int64_t)b * a.q1_item_stride + (int64_t)i * a.ldq1 + 4 * hd);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (g == (hd >> 1)) { f[4 * g] = q.x * qs; f[4 * g + 1] = q.y * qs; f[4 * g + 2] = q.z * qs; f[4 * g + 3] = q.w * qs; }
@@ -688,6 +784,7 @@ hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream) {
 hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     if (a0.B <= 0 || a0.L <= 0 || !a0.image || !a0.packed || !a0.att0 || !a0.x0_time || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
     EncRowsArgs a = a0;
+    if (a.q1_item_stride == 0) a.q1_item_stride = (int64_t)a.L * a.ldq1;
     a.img_f32 = reinterpret_cast<const float*>(a.image);
     a.img_bf = reinterpret_cast<const unsigned short*>(a.img_f32 + IMG_F32_FLOATS);
     const size_t smem = IMG_F32_FLOATS * 4 + (VEC_FLOATS + 64) * 4;
@@ -697,17 +794,32 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     int blocks = (int)((tiles + wpb - 1) / wpb);
     const int cap = 256 * (waves == 3 ? 3 : 2);        // resident workgroups; waves stride over the remaining tiles
     if (blocks > cap) blocks = cap;
-#define ADX_LAUNCH_ROWS2(P, G)                                                                                          \
-    do {                                                                                                               \
-        if (waves == 4) hipLaunchKernelGGL((enc_rows_kernel<P, 4, G>), dim3(blocks), dim3(512), smem, stream, a);      \
-        else if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3, G>), dim3(blocks), dim3(256), smem, stream, a); \
-        else hipLaunchKernelGGL((enc_rows_kernel<P, 2, G>), dim3(blocks), dim3(256), smem, stream, a);                 \
+#define ADX_LAUNCH_ROWS2(P, G, T)                                                                                          \
+    do {                                                                                                                  \
+        if (waves == 4) hipLaunchKernelGGL((enc_rows_kernel<P, 4, G, T>), dim3(blocks), dim3(512), smem, stream, a);      \
+        else if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3, G, T>), dim3(blocks), dim3(256), smem, stream, a); \
+        else hipLaunchKernelGGL((enc_rows_kernel<P, 2, G, T>), dim3(blocks), dim3(256), smem, stream, a);                 \
     } while (0)
 #define ADX_LAUNCH_ROWS(P)                                       \
     do {                                                         \
-        if (a.gpk) ADX_LAUNCH_ROWS2(P, true);                    \
-        else ADX_LAUNCH_ROWS2(P, false);                         \
+        if (a.gpk && a.gates && abl && waves == 3) {             \
+            switch (abl) {                                       \
+                case 1: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 1>), dim3(blocks), dim3(256), smem, stream, a); break;  \
+                case 2: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 2>), dim3(blocks), dim3(256), smem, stream, a); break;  \
+                case 3: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 3>), dim3(blocks), dim3(256), smem, stream, a); break;  \
+                case 4: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 4>), dim3(blocks), dim3(256), smem, stream, a); break;  \
+                case 8: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 8>), dim3(blocks), dim3(256), smem, stream, a); break;  \
+                case 12: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 12>), dim3(blocks), dim3(256), smem, stream, a); break; \
+                case 15: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 15>), dim3(blocks), dim3(256), smem, stream, a); break; \
+                default: ADX_LAUNCH_ROWS2(P, true, true);        \
+            }                                                    \
+        } else if (a.gpk && a.gates) ADX_LAUNCH_ROWS2(P, true, true);   \
+        else if (a.gpk) ADX_LAUNCH_ROWS2(P, true, false);        \
+        else ADX_LAUNCH_ROWS2(P, false, false);                  \
     } while (0)
+    if (a.gates && !a.gpk) return hipErrorInvalidValue;          // the gate table exists for the LayerNorm-row form only
+    const char* abl_env = getenv("ADX_ENC_ROWS_ABLATE");         // measurement aid, read per call (split-bf16 mode only)
+    const int abl = (abl_env && prec == PREC_BF16X3) ? atoi(abl_env) : 0;
     if (!a.gpk && !a.kv) return hipErrorInvalidValue;
     if (prec == PREC_F32) ADX_LAUNCH_ROWS(PREC_F32);
     else if (prec == PREC_BF16) ADX_LAUNCH_ROWS(PREC_BF16);
@@ -717,13 +829,25 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
     return hipGetLastError();
 }
 
+size_t enc_rows_gates_bytes(int B, int L, int n_steps) { return (size_t)(((int64_t)B * L + 31) / 32) * 64 * sizeof(float4) * (size_t)n_steps; }
+
+hipError_t enc_rows_pack_gates(const EncRowsArgs& a, float4* gates, const float* tq, int n_steps, hipStream_t stream) {
+    if (a.B <= 0 || a.L <= 0 || !a.packed || !a.x0 || !a.q || !a.state || !gates || !tq || n_steps <= 0) return hipErrorInvalidValue;
+    const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32, n = tiles * 64;
+    hipLaunchKernelGGL(pack_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, const_cast<float4*>(a.packed), gates, tiles, tq, n_steps,
+                       a.scale * LOG2E_F);
+    return hipGetLastError();
+}
+
 size_t enc_rows_g_bytes(int B, int L) { return (size_t)(((int64_t)B * L + 31) / 32) * 4 * 64 * sizeof(float4); }
 
 bool attention_g_ok(int n_keep) { return n_keep >= 1 && n_keep * NH <= AG_COLS; }
 
-hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream) {
+hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream) {
+    AttnGArgs a = a0;
+    if (a.q1_item_stride == 0) a.q1_item_stride = (int64_t)a.L * a.ldq1;
     if (a.B <= 0 || a.L <= 0 || !attention_g_ok(a.n_keep) || a.n_keep > a.L || !a.gpk || !a.image || !a.vecs || !a.wk || !a.q1 || !a.O ||
-        (a.ldq1 & 3) != 0 || (a.ldo & 3) != 0 || (a.o_batch_stride & 3) != 0 || (int64_t)a.B * a.L >= (int64_t)1 << 31)
+        (a.ldq1 & 3) != 0 || (a.q1_item_stride & 3) != 0 || (a.ldo & 3) != 0 || (a.o_batch_stride & 3) != 0 || (int64_t)a.B * a.L >= (int64_t)1 << 31)
         return hipErrorInvalidValue;
     const float* img_f32 = reinterpret_cast<const float*>(a.image);
     const unsigned short* img_bf = reinterpret_cast<const unsigned short*>(img_f32 + IMG_F32_FLOATS);

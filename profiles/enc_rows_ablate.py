@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Where the time of the encoder row kernel goes: the kernel with parts removed (ADX_ENC_ROWS_ABLATE, results are wrong), timed in
+isolation at the bench batch; events on the launch stream."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+dev = torch.device("cuda:0")
+da = bench.build_model(dev, "bf16x3")
+maps, prior, noise = bench.make_inputs(B, 0, dev, 1)
+out = torch.empty(B, 80, 4, device=dev)
+da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
+torch.cuda.synchronize()
+eng = da.diffusion.diffusion.model.engine()
+names = {0: "everything", 1: "identity instead of GELU", 2: "no FFN products", 3: "no FFN products, no GELU", 4: "no stores", 8: "inputs from L2 (every tile re-reads the first)",
+         12: "no stores, inputs from L2", 15: "no FFN, no GELU, no stores, inputs from L2"}
+for abl, name in names.items():
+    os.environ["ADX_ENC_ROWS_ABLATE"] = str(abl)
+    eng.debug_stage_a(B, 1, 5)
+    best = 1e9
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        eng.debug_stage_a(B, 1, 20)
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / 20 * 1e3)
+    print(f"enc_rows B={B} {name:50s} {best:7.1f} us", flush=True)
+os.environ.pop("ADX_ENC_ROWS_ABLATE", None)
