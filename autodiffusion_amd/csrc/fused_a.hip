@@ -155,23 +155,34 @@ __device__ __forceinline__ f32x16 mm_w(const WFrag& w, const f32x16& in, f32x16 
     return acc;
 }
 
-// GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), with Phi(-t) = 2^q(t) and q a degree-6 polynomial fitted to
-// log2 Phi(-t) on [0, 5.6] (weighted minimax for the error of the product; beyond 5.6 the term is below 1e-7 and t is
-// clamped).  |error| <= 3e-7 over the whole line, with one transcendental and no division: the exponential and the
+// GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|), with Phi(-t) = 2^q(t) and q a degree-5 polynomial fitted to
+// log2 Phi(-t) on [0, 5.6] (minimax for the error of the product; beyond 5.6 the term is below 1e-7 and t is
+// clamped).  |error| <= 9e-7 over the whole line evaluated in fp32 (4.6e-7 in exact arithmetic; a sixth-degree fit reaches
+// 5e-7 in fp32, so the last coefficient bought nothing), with one transcendental and no division: the exponential and the
 // reciprocal of the erfc formulas are quarter-rate instructions and this kernel is bound by vector issue.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per call: the polynomial runs on packed fp32 FMAs
     const f32x2 av = __builtin_elementwise_abs(v);
     const f32x2 t = __builtin_elementwise_min(av, f32x2{5.6f, 5.6f});
-    f32x2 q = t * 3.309289604658261e-05f + -0.0007692204089835286f;
-    q = t * q + 0.008080719038844109f;
-    q = t * q + -0.05341210588812828f;
-    q = t * q + -0.4587709605693817f;
-    q = t * q + -1.1512017250061035f;
-    q = t * q + -0.999993085861206f;
+    f32x2 q = t * -4.72791765e-04f + 7.08039424e-03f;
+    q = t * q + -5.18154655e-02f;
+    q = t * q + -4.60007281e-01f;
+    q = t * q + -1.15078008e+00f;
+    q = t * q + -1.00003892e+00f;
     const f32x2 e = {exp2_fast(q.x), exp2_fast(q.y)};
     return __builtin_elementwise_max(v, f32x2{0.f, 0.f}) - av * e;
+}
+
+// the same function on one value with plain (unpacked) FMAs: measurement aid for the packed form
+__device__ __forceinline__ float gelu_erf1(float v) {
+    const float av = fabsf(v), t = fminf(av, 5.6f);
+    float q = fmaf(t, -4.72791765e-04f, 7.08039424e-03f);
+    q = fmaf(t, q, -5.18154655e-02f);
+    q = fmaf(t, q, -4.60007281e-01f);
+    q = fmaf(t, q, -1.15078008e+00f);
+    q = fmaf(t, q, -1.00003892e+00f);
+    return fmaf(-av, exp2_fast(q), fmaxf(v, 0.f));
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -353,8 +364,8 @@ __device__ __forceinline__ void land_row(RowIn& in) {
 // workgroups per CU) or 8 waves (WAVES = 4, two workgroups per CU), so that the LDS copies of the weight image fit.
 // GOUT: the kernel ends at the layer-1 LayerNorm and stores those rows (lane order, one float4 per lane and register group:
 // four stores of 1 KB of contiguous memory per tile) for attention_g instead of projecting and storing K | V.
-// ABL: measurement aid (results are wrong): 1 the FFN activation is the identity, 2 no FFN products, 4 no stores of the row output,
-// 8 every tile re-reads the wave's first tile (L2 hits instead of HBM)
+// ABL: measurement aid (results are wrong except for 16): 1 the FFN activation is the identity, 2 no FFN products, 4 no stores of
+// the row output, 8 every tile re-reads the wave's first tile (L2 hits instead of HBM), 16 GELU with unpacked FMAs (same bits)
 template <int PREC, int WAVES, bool GOUT, bool GATES, int ABL = 0>
 __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
     constexpr int NT = WAVES == 4 ? 512 : 256;
@@ -458,8 +469,10 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 b = bb[g];
-                    const f32x2 lo = (ABL & 1) ? f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y} : gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
-                    const f32x2 hi = (ABL & 1) ? f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w} : gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
+                    const f32x2 lo = (ABL & 1) ? f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y}
+                                     : (ABL & 16) ? f32x2{gelu_erf1(f[4 * g + 0] + b.x), gelu_erf1(f[4 * g + 1] + b.y)} : gelu_erf2(f32x2{f[4 * g + 0] + b.x, f[4 * g + 1] + b.y});
+                    const f32x2 hi = (ABL & 1) ? f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w}
+                                     : (ABL & 16) ? f32x2{gelu_erf1(f[4 * g + 2] + b.z), gelu_erf1(f[4 * g + 3] + b.w)} : gelu_erf2(f32x2{f[4 * g + 2] + b.z, f[4 * g + 3] + b.w});
                     f[4 * g + 0] = lo.x; f[4 * g + 1] = lo.y; f[4 * g + 2] = hi.x; f[4 * g + 3] = hi.y;
                 }
                 w1 = load_w(img, tile_base(1) + min(nt + 1, 3), lane);          // lands under the MFMAs below
@@ -811,6 +824,7 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
                 case 8: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 8>), dim3(blocks), dim3(256), smem, stream, a); break;  \
                 case 12: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 12>), dim3(blocks), dim3(256), smem, stream, a); break; \
                 case 15: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 15>), dim3(blocks), dim3(256), smem, stream, a); break; \
+                case 16: hipLaunchKernelGGL((enc_rows_kernel<P, 3, true, true, 16>), dim3(blocks), dim3(256), smem, stream, a); break; \
                 default: ADX_LAUNCH_ROWS2(P, true, true);        \
             }                                                    \
         } else if (a.gpk && a.gates) ADX_LAUNCH_ROWS2(P, true, true);   \

@@ -74,8 +74,13 @@ def time_kernel(fn, iters=20):
 # HBM bytes of one launch of the encoder row kernel at B = 1024 from the L2 fabric-request counters (separate rocprofv3
 # --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
 # the per-row figure scales with B.  Source: profiles/r02_pmc_refiner.txt.
-ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (2699403.8 * 128 + 1702047.8 * 64) / (1024 * L_COND)
-ENC_ROWS_READ_BYTES_PER_ROW = 416            # x0 (128) + layer-0 query (128) + normalised softmax state (160)
+ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (1870561.6 * 128 + 1701910.1 * 64) / (1024 * L_COND)
+def enc_rows_read_bytes_per_row(B, n_steps):
+    """x0 (128) + the cached attention output o / l (128) + this step's gates (32) while the per-chunk gate table fits the
+    engine's budget (its rule, ADX_GATE_TABLE_MAX_MB included); otherwise x0 + layer-0 query (128) + normalised state (160)."""
+    budget = int(os.environ.get("ADX_GATE_TABLE_MAX_MB", "16384")) << 20
+    need = n_steps * ((B * L_COND + 31) // 32) * 1024
+    return 288 if 0 < need <= budget else 416
 
 
 def enc_rows_write_bytes_per_row(fs):
@@ -87,9 +92,10 @@ def enc_rows_write_bytes_per_row(fs):
 def roofline(da, B, step):
     """Dominant kernel of a denoiser call: the fused encoder row pipeline (enc_rows_kernel), one launch per call.
 
-    It streams every conditioning row once -- 544 algorithmic bytes per row (416 read, 128 written), B * 809 rows per
-    launch -- and does 18.4 kflop per row on the matrix cores, so HBM bandwidth is the roof that binds (56 us at 8 TB/s
-    against 6 us at the dense bf16 MFMA peak, B = 1024).  Its launches are timed inside one more pass of the workload: the engine brackets
+    It streams every conditioning row once -- 416 algorithmic bytes per row (288 read, 128 written), B * 809 rows per
+    launch -- and does 18.4 kflop per row on the matrix cores, so of the two roofs HBM bandwidth is the one that binds
+    (43 us at 8 TB/s against 6 us at the dense bf16 MFMA peak, B = 1024); what actually limits the kernel is vector
+    issue (GELU and operand conversions: profiles/r02_enc_rows_ablation.txt).  Its launches are timed inside one more pass of the workload: the engine brackets
     every marked launch with events on the launch stream (no graph capture during that pass).  ``stages_us`` lists the
     other kernels of a call from the same pass.
     """
@@ -109,11 +115,12 @@ def roofline(da, B, step):
         eng.profile(False)
     rows = B * L_COND
     wr = enc_rows_write_bytes_per_row(FS)
-    algo = float((ENC_ROWS_READ_BYTES_PER_ROW + wr) * rows)
+    rd = enc_rows_read_bytes_per_row(B, N_SAMPLE if N_SAMPLE < N_TRAIN else N_TRAIN)
+    algo = float((rd + wr) * rows)
     achieved = algo / t["enc_rows"] / 1e9
     return {"kernel": "enc_rows_kernel (encoder layer 0 after its attention + layer 1 LayerNorm over all conditioning rows)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows) if wr == 128 and FS == 10 else None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
+            "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows) if wr == 128 and rd == 288 and FS == 10 else None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
             "launches_timed": launches, "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()}}
 
 

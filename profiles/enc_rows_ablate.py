@@ -17,7 +17,7 @@ out = torch.empty(B, 80, 4, device=dev)
 da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
 torch.cuda.synchronize()
 eng = da.diffusion.diffusion.model.engine()
-names = {0: "everything", 1: "identity instead of GELU", 2: "no FFN products", 3: "no FFN products, no GELU", 4: "no stores", 8: "inputs from L2 (every tile re-reads the first)",
+names = {0: "everything", 16: "GELU with unpacked FMAs (same results)", 1: "identity instead of GELU", 2: "no FFN products", 3: "no FFN products, no GELU", 4: "no stores", 8: "inputs from L2 (every tile re-reads the first)",
          12: "no stores, inputs from L2", 15: "no FFN, no GELU, no stores, inputs from L2"}
 for abl, name in names.items():
     os.environ["ADX_ENC_ROWS_ABLATE"] = str(abl)
