@@ -568,6 +568,31 @@ def test_last_attention_forms_agree(dev, fs):
     assert rel_err(outs["1"], ref) < GATE and rel_err(outs["0"], ref) < GATE
 
 
+def test_gate_table_same_bits(dev):
+    """The row kernel reads the gates of the time-token fold from a per-chunk table (every step's gates computed once per chunk)
+    or evaluates them itself (ADX_GATE_TABLE_MAX_MB=0, what schedules too long for the table's budget take).  Both use the same
+    expressions: the sampled trajectories are bit-identical, in fp32 and with split-bf16 operands; the third-stream form of
+    the step pipeline (ADX_OVERLAP_STREAMS=3) only reorders launches and must return the same bits as well."""
+    from autodiffusion_amd import synth
+    fs, B, N = 10, 5, 10
+    noise = synth.noise(B, (8, N), (fs, 4), NSEED).to(dev)
+    prior = synth.trajectory_prior(B, ISEED).to(dev)
+    maps = synth.maps_info(B, ISEED).to(dev)
+    for prec in ("fp32", "bf16x3"):
+        outs = []
+        for env in ({}, {"ADX_GATE_TABLE_MAX_MB": "0"}, {"ADX_OVERLAP_STREAMS": "3"}):
+            os.environ.update(env)
+            try:
+                da = _make_da(fs, N, prec, "seeded", dev)
+                outs.append(da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].clone())
+                outs.append(da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].clone())     # graph replay
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), prec
+
+
 def test_full_size_properties(dev):
     """The bench configuration at full size (4096 scenarios, DDIM 50 of 100, split-bf16 operands), through properties that
     do not need a full-size oracle: two runs are bit-identical; the first and the last rows equal what a 3-row batch of the same
