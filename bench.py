@@ -121,7 +121,9 @@ def roofline(da, B, step):
     return {"kernel": "enc_rows_kernel (encoder layer 0 after its attention + layer 1 LayerNorm over all conditioning rows)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows) if wr == 128 and rd == 288 and FS == 10 else None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
-            "launches_timed": launches, "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()}}
+            "launches_timed": launches, "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()},
+            "note": "HBM is the binding one of the two roofs, but the kernel is limited by vector issue: with no HBM traffic at all "
+                    "(no stores, inputs from L2) it still takes 80 of its 96 us (profiles/r02_enc_rows_ablation.txt)"}
 
 
 # ------------------------------------------------------------------------------------------------ DiT decoder workloads
