@@ -612,6 +612,20 @@ __device__ __forceinline__ f32x16 mma(const Opnd<PREC>& A, const Opnd<PREC>& B, 
     return acc;
 }
 
+// N products issued with their accumulation chains interleaved: consecutive matrix instructions never depend on each other
+template <int N>
+__device__ __forceinline__ void mma_x3_interleaved(const Opnd<PREC_BF16X3>* const (&A)[N], const Opnd<PREC_BF16X3>* const (&B)[N], f32x16 (&acc)[N]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[n]->h[s], B[n]->l[s], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[n]->l[s], B[n]->h[s], acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[n]->h[s], B[n]->h[s], acc[n], 0, 0, 0);
+    }
+}
+
 constexpr int AG_COLS = 96;            // (visible row, head) pairs: three 32-wide column blocks
 constexpr float AG_NEG = -1.0e30f;
 
@@ -702,6 +716,20 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
                 if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
                 else return to_opnd<PREC>(sc);
             };
+            if constexpr ((ABL & 16) != 0 && PREC == PREC_BF16X3) {
+                // measurement aid: the same products with interleaved accumulation chains and no hand placement of vector work
+                const Opnd<PREC> q0 = qsh[0][lane], q1 = qsh[1][lane], q2 = qsh[2][lane];
+                const Opnd<PREC>* const A4[4] = {&gop, &gop, &gop, &gop};
+                const Opnd<PREC>* const B4[4] = {&q0, &q1, &q2, &wv};
+                f32x16 acc4[4] = {zero16(), zero16(), zero16(), zero16()};
+                mma_x3_interleaved<4>(A4, B4, acc4);
+                const Opnd<PREC> vop = to_opnd<PREC>(acc4[3]);
+                const Opnd<PREC> p0 = soft(0, acc4[0]), p1 = soft(1, acc4[1]), p2 = soft(2, acc4[2]);
+                const Opnd<PREC>* const A3[3] = {&vop, &vop, &vop};
+                const Opnd<PREC>* const B3[3] = {&p0, &p1, &p2};
+                mma_x3_interleaved<3>(A3, B3, o);
+                return;
+            }
             const f32x16 s0 = (ABL & 4) ? g16 : mma<PREC>(gop, qsh[0][lane], zero16());
             __builtin_amdgcn_sched_barrier(0);
             // the other products of these rows (18 matrix instructions), with block 0's vector work between them
@@ -882,6 +910,7 @@ hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream) {
             case 8: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 8>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
             case 9: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 9>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
             case 15: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 15>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
+            case 16: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 16>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
             default: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
         }
     }
