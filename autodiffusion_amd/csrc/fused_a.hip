@@ -638,7 +638,7 @@ constexpr float AG_NEG = -1.0e30f;
 //     O^T += V^T P^T      (lane <-> column, registers <-> feature), P = 2^(S - running max): the online softmax keeps its
 //                          maximum, sum and rescale factor per LANE, because a column lives on a lane in S^T and in O^T alike.
 // Only the four features of a column's own head are meaningful in O^T; they are picked at the end.
-template <int PREC, int ABL = 0>      // ABL: measurement aid (results are wrong): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights
+template <int PREC, int ABL = 0>      // ABL: measurement aid (results are wrong except for 16): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights, 16 hand-placed instruction order
 __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
     __shared__ float mrg[(6 + 48) * 64];
     __shared__ Opnd<PREC> qsh[3][64];
@@ -716,8 +716,10 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
                 if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
                 else return to_opnd<PREC>(sc);
             };
-            if constexpr ((ABL & 16) != 0 && PREC == PREC_BF16X3) {
-                // measurement aid: the same products with interleaved accumulation chains and no hand placement of vector work
+            if constexpr (ABL == 0 && PREC == PREC_BF16X3) {          // (the measurement variants remove parts of the hand-placed form below)
+                // split-bf16 operands: the four products of these rows, then the three weighted sums, each set issued with its
+                // accumulation chains interleaved (no matrix instruction depends on its predecessor): 45.5 us against 48.3 us for
+                // the hand-placed order below (ADX_ATTN_G_ABLATE=16), same bits
                 const Opnd<PREC> q0 = qsh[0][lane], q1 = qsh[1][lane], q2 = qsh[2][lane];
                 const Opnd<PREC>* const A4[4] = {&gop, &gop, &gop, &gop};
                 const Opnd<PREC>* const B4[4] = {&q0, &q1, &q2, &wv};

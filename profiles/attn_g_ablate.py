@@ -17,7 +17,7 @@ out = torch.empty(B, 80, 4, device=dev)
 da.generate(trajectory_prior=prior, maps_info=maps, noise=noise, out=out)
 torch.cuda.synchronize()
 eng = da.diffusion.diffusion.model.engine()
-names = {0: "everything", 16: "interleaved accumulation chains (same results)", 1: "no exponentials", 2: "no weighted-sum products", 4: "no score products", 6: "no score and weighted-sum products",
+names = {0: "everything", 16: "hand-placed order instead of interleaved chains (same results)", 1: "no exponentials", 2: "no weighted-sum products", 4: "no score products", 6: "no score and weighted-sum products",
          8: "no split of the weights", 9: "no exponentials, no split of the weights", 15: "loads, V projection and bookkeeping only"}
 for abl, name in names.items():
     os.environ["ADX_ATTN_G_ABLATE"] = str(abl)
