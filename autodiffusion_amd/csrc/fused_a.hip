@@ -275,12 +275,18 @@ struct RowInG {
 };
 constexpr int PACK_VECS_G = 8;
 
+__device__ __forceinline__ float4 ld_stream(const float4* p) {       // read once per step, 240 MB per launch: do not keep it in the caches
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 __device__ __forceinline__ void load_row(RowInG& in, const float4* __restrict__ p, const float4* __restrict__ gp) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) in.x[g] = p[64 * g];
+    for (int g = 0; g < 4; ++g) in.x[g] = ld_stream(p + 64 * g);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) in.o[g] = p[64 * (4 + g)];
-    in.gate = *gp;
+    for (int g = 0; g < 4; ++g) in.o[g] = ld_stream(p + 64 * (4 + g));
+    in.gate = ld_stream(gp);
 }
 
 __device__ __forceinline__ void land_row(RowInG& in) {
@@ -337,7 +343,9 @@ __global__ __launch_bounds__(256) void pack_gates_kernel(const EncRowsArgs a, fl
                     const float sv = fmaf(q[g].x, kk.x, fmaf(q[g].y, kk.y, fmaf(q[g].z, kk.z, q[g].w * kk.w)));
                     gt[g] = rcp_fast(1.0f + exp2_fast(c[g] - sv));
                 }
-                gates[((int64_t)(s0 + k) * n_tiles + tile) * 64 + lane] = make_float4(gt[0], gt[1], gt[2], gt[3]);
+                // streamed: written once here, read once by the step that uses it, 26 MB apart from its neighbours in time
+                typedef __attribute__((ext_vector_type(4))) float v4;
+                __builtin_nontemporal_store(v4{gt[0], gt[1], gt[2], gt[3]}, reinterpret_cast<v4*>(gates + ((int64_t)(s0 + k) * n_tiles + tile) * 64 + lane));
             }
         }
     }
@@ -680,7 +688,7 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
         const int64_t row = min(r0 + 32 * (int64_t)min(grp, n_groups - 1) + n, r1 - 1);
         const float4* gp = a.gpk + (row >> 5) * (4 * 64) + h2 * 32 + (row & 31);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gv[g] = gp[64 * g];
+        for (int g = 0; g < 4; ++g) gv[g] = gp[64 * g];          // written by the row kernel just before: kept cacheable (streamed loads measured 1 % slower)
     };
     fetch(t);
     for (; t < n_groups; t += 2) {
