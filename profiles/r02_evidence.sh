@@ -20,6 +20,9 @@ pmc() {     # pmc <tag> "<counters>" <filter> <command...>: one counter pass -> 
 if [ $part = all ] || [ $part = bench ]; then
     timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $O/bench_b1024.json 2> $O/bench.err && cut -c1-400 $O/bench_b1024.json
     trace refiner_b1024 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+    # the same command with every kernel of a step on one stream: the per-kernel averages the events inside bench.py report
+    # (its roofline pass runs un-overlapped); in the overlapped trace above the kernels stretch because the tail shares the CUs
+    ADX_NO_OVERLAP=1 trace refiner_b1024_one_stream python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
 fi
 if [ $part = all ] || [ $part = pmcref ]; then
     rm -f $O/pmc_refiner_b1024.txt
