@@ -252,7 +252,7 @@ def dit_gemm(dev):
         y = torch.empty(M, N, device=dev)
         product = lambda k: [ops.linear_planes(xp, wp, bias, M, N, K, precision=prec, out=y) for _ in range(k)]  # noqa: E731
         whole = lambda k: [ops.linear(x, w, bias, precision=prec, prepared_n=N, workspace=ws) for _ in range(k)]  # noqa: E731
-        product(60)                                          # the clocks of an idle GPU take tens of ms to ramp up
+        product(200)                                         # an idle GPU needs ~150 of these launches (60 ms) before its clocks settle (profiles/gemm_warm_probe.py)
         t = min(time_kernel(product, 20) for _ in range(3))
         t_whole = min(time_kernel(whole, 20) for _ in range(3))
         tf, tf_whole = 2.0 * M * N * K / t / 1e12, 2.0 * M * N * K / t_whole / 1e12

@@ -32,7 +32,7 @@ for prec in sys.argv[1:] or ["bf16x3", "bf16"]:
             for _ in range(n):
                 y = ops.linear(x, w, b, precision=prec, prepared_n=N, workspace=ws)
             return y
-        ys = {f: run(f, 20) for f in forms}
+        ys = {f: run(f, 100 if (M, N, K) == shapes[0] else 20) for f in forms}      # the first shape also pays for the clock ramp of an idle GPU
         ref_rows = slice(0, 512)
         xr, wr = (x[ref_rows].bfloat16().double(), w32.bfloat16().double()) if prec == "bf16" else (x[ref_rows].double(), w32.double())
         ref = (xr @ wr.T + b.double()).float()
@@ -51,7 +51,7 @@ for prec in sys.argv[1:] or ["bf16x3", "bf16"]:
         if "2" in forms and K >= 512:            # the product kernel alone, operands already in planes (what the decoder launches)
             os.environ["ADX_GLDS_FORM"] = "2"
             xp, wp, y = ops.stage_planes(x, prec), ops.block_weight(w, N, K, prec), torch.empty(M, N, device=dev)
-            for _ in range(20):
+            for _ in range(150 if (M, N, K) == shapes[0] else 20):
                 ops.linear_planes(xp, wp, b, M, N, K, precision=prec, out=y)
             assert torch.equal(y, ys["2"])
             us = float("inf")
