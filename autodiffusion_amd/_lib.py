@@ -27,7 +27,7 @@ EXPORTS = [
     "adx_op_normalize", "adx_op_denormalize", "adx_op_sched_step",
     "adx_engine_create", "adx_engine_destroy", "adx_engine_set_tensor", "adx_engine_finalize", "adx_engine_reserve",
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
-    "adx_generate_a", "adx_sample_dit", "adx_debug_stage_a", "adx_op_select_modes", "adx_op_trajectory_metrics", "adx_engine_profile", "adx_engine_profile_read",
+    "adx_generate_a", "adx_sample_dit", "adx_sample_dit_grouped", "adx_debug_stage_a", "adx_op_select_modes", "adx_op_trajectory_metrics", "adx_engine_profile", "adx_engine_profile_read",
     "adx_engine_set_noise_seed", "adx_op_randn", "adx_engine_capture_count", "adx_op_q_sample", "adx_op_weighted_mse",
     "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes",
 ]
@@ -89,6 +89,7 @@ def load() -> C.CDLL:
         "adx_sample_a": ([p, i, p, p, p, p, i, p, p, p, u, p], i),
         "adx_generate_a": ([p, i, i, i, p, p, p, p, i, p, u, p], i),
         "adx_sample_dit": ([p, i, p, p, i, p, u, p], i),
+        "adx_sample_dit_grouped": ([p, i, i, p, p, i, p, u, p], i),
         "adx_debug_stage_a": ([p, i, i, i, p], i),
         "adx_engine_profile": ([p, i], i),
         "adx_op_trajectory_metrics": ([p, p, i, i, i, p, p], i),

@@ -29,7 +29,8 @@ struct LinearArgs {
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
     int in_act = ACT_NONE;              // activation applied to X while it is staged (SiLU for adaLN)
-    const float* gate = nullptr; int64_t ldg = 0;   // [M][N], rows follow ymap
+    const float* gate = nullptr; int64_t ldg = 0;   // [M][N], rows follow ymap ...
+    int gate_group = 0, gate_period = 0;            // ... or, with gate_group > 0, row (r / gate_group) * gate_period + r % gate_period (shared conditioning)
     const float* res = nullptr;  int64_t ldr = 0;   // [M][N], rows follow ymap
     const float* pos = nullptr;  int64_t ldp = 0; int pos_period = 0; int pos_off = 0;  // + pos[(m % period) + off][n]
     // column map of Y: col n -> (n / col_group) * col_stride + (n % col_group) + col_off (identity when col_group == 0)
@@ -66,6 +67,9 @@ struct LayerNormArgs {
     const float* gamma = nullptr; const float* beta = nullptr;      // [d]
     const float* shift = nullptr; const float* scale = nullptr; int64_t ldm = 0;  // [rows][d] slices, identity row map
     const float* gate = nullptr; int64_t ldg = 0;   // y = res + gate * (...) ; [rows][d], identity row map
+    // rows that share their conditioning (several samples of one scenario): shift / scale / gate of row r are read from row
+    // (r / mod_group) * mod_period + r % mod_period of those tables (mod_group 0: row r itself)
+    int mod_group = 0, mod_period = 0;
     const float* res = nullptr; int64_t ldr = 0;
     float eps = 1e-5f;
     int rows = 0, d = 0;

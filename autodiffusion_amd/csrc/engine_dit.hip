@@ -178,10 +178,17 @@ struct EngineDiT final : adx_engine {
         a.pl = (ph && cfg.precision == ADX_PREC_BF16X3) ? ph + (size_t)R * d : nullptr;
     }
 
+    // Samples of one scenario share their conditioning: with a sample group G > 1, rows (b G + g) S + tok of the token buffers
+    // read the modulation row b S + tok -- every conditioning-only tensor (state embedding, SiLU input, adaLN outputs) has
+    // B / G items instead of B.
+    int group = 1;                          // set per call by sample(); 1 everywhere else
+    int mod_group() const { return group > 1 ? group * S : 0; }
+
     int ln_mod(const float* x, float* y, const float* mod, int ld_mod, int shift_chunk, int R, hipStream_t s, unsigned short* ph = nullptr) {
         LayerNormArgs a;
         set_planes(a, ph, R);
         a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.eps = 1e-6f; a.rows = R; a.d = d;
+        a.mod_group = mod_group(); a.mod_period = S;
         a.shift = mod + (int64_t)shift_chunk * d; a.scale = mod + (int64_t)(shift_chunk + 1) * d; a.ldm = ld_mod;
         ADX_HIP(layernorm(a, s));
         return ADX_OK;
@@ -194,6 +201,7 @@ struct EngineDiT final : adx_engine {
         a.x = x; a.ldx = d; a.y = y; a.ldy = d; a.eps = 1e-5f; a.rows = R; a.d = d;
         a.gamma = P(p + ".weight"); a.beta = P(p + ".bias");
         a.gate = gate; a.ldg = ldg; a.res = res; a.ldr = d;
+        if (gate) { a.mod_group = mod_group(); a.mod_period = S; }
         ADX_HIP(layernorm(a, s));
         return ADX_OK;
     }
@@ -202,10 +210,11 @@ struct EngineDiT final : adx_engine {
     // 0: one vector for all); SE must hold state_encoder(state).  out (B,S,C).
     int run_net(int B, const float* x, const float* te, int64_t rows_per_vec, float* out, hipStream_t s) {
         const int R = B * S;
+        const int Rc = R / group;               // conditioning rows (group > 1: several samples per scenario)
         ADX_HIP(copy2d(x, C, 0, x_cat[0], x_stages[0].in + x_stages[0].hidden, R, C, s));
         ADX_TRY(run_stages(x_stages, x_cat, R, HX, P("position_embedding"), s));
         // SiLU(t_emb + state_emb): the only use of the conditioning sum is through SiLU (adaLN inputs)
-        ADX_HIP(add_vec_act(SE, te, SIL, R, d, rows_per_vec, ACT_SILU, s));
+        ADX_HIP(add_vec_act(SE, te, SIL, Rc, d, rows_per_vec, ACT_SILU, s));
         if (!mm) {
             const int dh = d / H;
             // Operand planes: where the staged GEMM will take a product (enough tiles, long enough K), the kernel that PRODUCES
@@ -216,15 +225,15 @@ struct EngineDiT final : adx_engine {
             const bool planes = prec != ADX_PREC_F32 && HNP && (d % 256) == 0 && !(pl_env && pl_env[0] == '0');
             const bool pk_d = planes && linear_planes_ok(R, 3 * d, d, prec) && linear_planes_ok(R, 4 * d, d, prec);
             const bool pk_4d = planes && linear_planes_ok(R, d, 4 * d, prec);
-            const bool pk_sil = planes && linear_planes_ok(R, 6 * d, d, prec);
+            const bool pk_sil = planes && linear_planes_ok(Rc, 6 * d, d, prec);
             const bool x3 = prec == ADX_PREC_BF16X3;
             auto use_planes = [&](LinearArgs& a, const unsigned short* ph, int K) { a.Xh = ph; a.Xl = x3 ? ph + (size_t)R * K : nullptr; };
             auto out_planes = [&](LinearArgs& a, unsigned short* ph, int N) { a.Y = nullptr; a.Yh = ph; a.Yl = x3 ? ph + (size_t)R * N : nullptr; };
-            if (pk_sil) ADX_HIP(stage_planes(SIL, d, R, d, ACT_NONE, SILP, x3 ? SILP + (size_t)R * d : nullptr, s));
+            if (pk_sil) ADX_HIP(stage_planes(SIL, d, Rc, d, ACT_NONE, SILP, x3 ? SILP + (size_t)Rc * d : nullptr, s));
             for (int i = 0; i < NL; ++i) {
                 const std::string p = "blocks." + std::to_string(i);
-                LinearArgs ada = lin(SIL, d, p + ".adaLN_modulation.1.weight", 0, 6 * d, d, p + ".adaLN_modulation.1.bias", MOD, 6 * d, R);
-                if (pk_sil) use_planes(ada, SILP, d);
+                LinearArgs ada = lin(SIL, d, p + ".adaLN_modulation.1.weight", 0, 6 * d, d, p + ".adaLN_modulation.1.bias", MOD, 6 * d, Rc);
+                if (pk_sil) { ada.Xh = SILP; ada.Xl = x3 ? SILP + (size_t)Rc * d : nullptr; }
                 ADX_HIP(linear(ada, s));
                 ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 0, R, s, pk_d ? HNP : nullptr));
                 // post-norm ReLU encoder layer on HN
@@ -260,6 +269,7 @@ struct EngineDiT final : adx_engine {
                 LinearArgs m2 = lin(FF, 4 * d, p + ".mlp.2.weight", 0, d, 4 * d, p + ".mlp.2.bias", HX, d, R, ACT_GELU_TANH);
                 if (pk_4d) use_planes(m2, FFP, 4 * d);
                 m2.gate = MOD + 5 * d; m2.ldg = 6 * d; m2.res = HX; m2.ldr = d;
+                m2.gate_group = mod_group(); m2.gate_period = S;
                 ADX_HIP(linear(m2, s));
             }
         } else {
@@ -307,7 +317,7 @@ struct EngineDiT final : adx_engine {
             }
         }
         // final layer
-        ADX_HIP(linear(lin(SIL, d, "final_layer.adaLN_modulation.1.weight", 0, 2 * d, d, "final_layer.adaLN_modulation.1.bias", MODF, 2 * d, R), s));
+        ADX_HIP(linear(lin(SIL, d, "final_layer.adaLN_modulation.1.weight", 0, 2 * d, d, "final_layer.adaLN_modulation.1.bias", MODF, 2 * d, Rc), s));
         ADX_TRY(ln_mod(HX, HN, MODF, 2 * d, 0, R, s));
         ADX_HIP(linear(lin(HN, d, "final_layer.linear.weight", 0, C, d, "final_layer.linear.bias", out, C, R, ACT_NONE, PREC_F32), s));
         return ADX_OK;
@@ -328,8 +338,11 @@ struct EngineDiT final : adx_engine {
         return run_net(B, x, TEB, S, out, s);
     }
 
-    int sample(int B, const float* state, const float* noise, int n_noise, float* out, unsigned flags, hipStream_t s) {
+    // G > 1: the B sample rows come in groups of G consecutive rows that share their conditioning; `state` then holds B / G items
+    int sample(int B, const float* state, const float* noise, int n_noise, float* out, unsigned flags, hipStream_t s, int G = 1) {
         ADX_TRY(check_ready(B, "sample_dit"));
+        if (G < 1 || B % G != 0) { set_error("sample_dit: the batch must be a multiple of the sample group"); return ADX_EINVAL; }
+        if (G > 1 && mm) { set_error("sample_dit: sample groups need the DiT backbone (the MM-DiT conditioning stream depends on the sample)"); return ADX_EINVAL; }
         if (steps.empty()) { set_error("sample_dit: no schedule set"); return ADX_ESTATE; }
         if (cfg.in_dim != cfg.out_dim) { set_error("sample_dit: in_dim must equal out_dim"); return ADX_EINVAL; }
         const int64_t n = (int64_t)B * S * C;
@@ -344,10 +357,10 @@ struct EngineDiT final : adx_engine {
                 set_error("sample_dit: schedule draws more noise tensors than were supplied"); return ADX_EINVAL;
             }
         char shape[160], ptrs[120];
-        snprintf(shape, sizeof shape, "d|%d|%d|%u|%d|%d", B, n_noise, flags, schedule_version, (int)dev_noise);
+        snprintf(shape, sizeof shape, "d|%d|%d|%u|%d|%d|g%d", B, n_noise, flags, schedule_version, (int)dev_noise, G);
         snprintf(ptrs, sizeof ptrs, "|%p|%p|%p", (const void*)state, dev_noise ? nullptr : (const void*)noise, (void*)out);
         const bool staged = use_staging(shape, ptrs, flags);
-        const size_t state_b = sizeof(float) * (size_t)B * S * d, out_b = sizeof(float) * (size_t)n;
+        const size_t state_b = sizeof(float) * (size_t)(B / G) * S * d, out_b = sizeof(float) * (size_t)n;
         const size_t noise_b = (noise && !dev_noise) ? sizeof(float) * (size_t)n_noise * n : 0;
         float* g_out = out;
         if (staged) {
@@ -366,7 +379,8 @@ struct EngineDiT final : adx_engine {
         const std::string key = std::string(shape) + (staged ? "|staged" : ptrs);
         const int rc = run(key, flags, s, [&](hipStream_t cs) -> int {
             if (dev_noise) ADX_HIP(randn_rows(noise_ctl, noise_buf, n_noise, B, S * C, cs));
-            ADX_TRY(encode_state(B, state, cs));
+            ADX_TRY(encode_state(B / G, state, cs));
+            group = G;
             float* xc = XS0; float* xn = XS1;
             if (flags & ADX_FLAG_INIT_ZERO) ADX_HIP(hipMemsetAsync(xc, 0, sizeof(float) * n, cs));
             else ADX_HIP(copy2d(noise, n, 0, xc, n, 1, (int)n, cs));
@@ -377,10 +391,12 @@ struct EngineDiT final : adx_engine {
                 ADX_HIP(sched_step(xc, MOUT, z, xn, nullptr, n, steps_dev + k, cs));
                 std::swap(xc, xn);
             }
+            group = 1;
             if (flags & ADX_FLAG_NORMALIZE) ADX_HIP(denormalize_traj(xc, nullptr, g_out, n / C, C, cs));
             else ADX_HIP(copy2d(xc, n, 0, g_out, n, 1, (int)n, cs));
             return ADX_OK;
         });
+        group = 1;
         if (rc == ADX_OK && staged) ADX_HIP(hipMemcpyAsync(out, g_out, out_b, hipMemcpyDeviceToDevice, s));
         return rc;
     }
@@ -419,4 +435,12 @@ ADX_API int adx_sample_dit(adx_engine* e, int B, const float* state, const float
     if (!a) return ADX_EINVAL;
     if (!state || !out) { set_error("sample_dit: null pointer"); return ADX_EINVAL; }
     return a->sample(B, state, noise, n_noise, out, flags, (hipStream_t)stream);
+}
+
+ADX_API int adx_sample_dit_grouped(adx_engine* e, int B, int group, const float* state, const float* noise, int n_noise, float* out,
+                                   unsigned flags, void* stream) {
+    EngineDiT* a = as_dit(e, "sample_dit_grouped");
+    if (!a) return ADX_EINVAL;
+    if (!state || !out) { set_error("sample_dit_grouped: null pointer"); return ADX_EINVAL; }
+    return a->sample(B, state, noise, n_noise, out, flags, (hipStream_t)stream, group);
 }

@@ -171,7 +171,7 @@ __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* 
             g[i] = zero; r[i] = zero;
             if constexpr (EXTRA) {
                 if (a.pos) p = *reinterpret_cast<const float4*>(a.pos + (int64_t)((mc % a.pos_period) + a.pos_off) * a.ldp + n);
-                if (a.gate) g[i] = *reinterpret_cast<const float4*>(a.gate + yrow * a.ldg + n);
+                if (a.gate) g[i] = *reinterpret_cast<const float4*>(a.gate + (a.gate_group ? (yrow / a.gate_group) * a.gate_period + yrow % a.gate_period : yrow) * a.ldg + n);
                 if (a.res) r[i] = *reinterpret_cast<const float4*>(a.res + yrow * a.ldr + n);
             }
             v[i][0] = raw.x + bvec.x + p.x; v[i][1] = raw.y + bvec.y + p.y; v[i][2] = raw.z + bvec.z + p.z; v[i][3] = raw.w + bvec.w + p.w;
@@ -246,7 +246,7 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
             if (a.bias) x += a.bias[ne];
             if (posrow) x += posrow[ne];
             x = act_fn(x, a.act);
-            if (a.gate) x *= a.gate[yrow * a.ldg + ne];
+            if (a.gate) x *= a.gate[(a.gate_group ? (yrow / a.gate_group) * a.gate_period + yrow % a.gate_period : yrow) * a.ldg + ne];
             if (a.res) x += a.res[yrow * a.ldr + ne];
             const int nc = a.col_group ? (ne / a.col_group) * a.col_stride + (ne % a.col_group) + a.col_off : ne;
             a.Y[yrow * a.ldy + nc] = x;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
                 if (a.bias) v += a.bias[n];
                 if (posrow) v += posrow[n];
                 v = apply_act(v, a.act);
-                if (a.gate) v *= a.gate[yrow * a.ldg + n];
+                if (a.gate) v *= a.gate[(a.gate_group ? (yrow / a.gate_group) * a.gate_period + yrow % a.gate_period : yrow) * a.ldg + n];
                 if (a.res) v += a.res[yrow * a.ldr + n];
                 const int nc = a.col_group ? (n / a.col_group) * a.col_stride + (n % a.col_group) + a.col_off : n;
                 a.Y[yrow * a.ldy + nc] = v;
@@ -293,14 +293,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormArgs a) {
     float q = 0.f;
     for (int c = lane; c < d; c += 64) { float t = x[c] - mean; q += t * t; }
     const float rstd = rsqrt_fast(wave_sum(q) / (float)d + a.eps);
-    const float* sh = a.shift ? a.shift + (int64_t)row * a.ldm : nullptr;
-    const float* sc = a.scale ? a.scale + (int64_t)row * a.ldm : nullptr;
+    const int64_t mrow = a.mod_group ? (int64_t)(row / a.mod_group) * a.mod_period + row % a.mod_period : (int64_t)row;
+    const float* sh = a.shift ? a.shift + mrow * a.ldm : nullptr;
+    const float* sc = a.scale ? a.scale + mrow * a.ldm : nullptr;
     for (int c = lane; c < d; c += 64) {
         float v = (x[c] - mean) * rstd;
         if (a.gamma) v = v * a.gamma[c] + a.beta[c];
         if (sc) v = v * (1.f + sc[c]) + sh[c];
         if (a.relu) v = v > 0.f ? v : 0.f;
-        if (a.gate) v *= a.gate[(int64_t)row * a.ldg + c];
+        if (a.gate) v *= a.gate[mrow * a.ldg + c];
         if (a.res) v += a.res[(int64_t)row * a.ldr + c];
         y[c] = v;
     }
@@ -328,11 +329,12 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs 
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float rstd = rsqrt_fast(wave_sum(q) * inv_d + a.eps);
-    const float4* sh = a.shift ? reinterpret_cast<const float4*>(a.shift + (int64_t)row * a.ldm) : nullptr;
-    const float4* sc = a.scale ? reinterpret_cast<const float4*>(a.scale + (int64_t)row * a.ldm) : nullptr;
+    const int64_t mrow = a.mod_group ? (int64_t)(row / a.mod_group) * a.mod_period + row % a.mod_period : (int64_t)row;
+    const float4* sh = a.shift ? reinterpret_cast<const float4*>(a.shift + mrow * a.ldm) : nullptr;
+    const float4* sc = a.scale ? reinterpret_cast<const float4*>(a.scale + mrow * a.ldm) : nullptr;
     const float4* ga = reinterpret_cast<const float4*>(a.gamma);
     const float4* be = reinterpret_cast<const float4*>(a.beta);
-    const float4* gt = a.gate ? reinterpret_cast<const float4*>(a.gate + (int64_t)row * a.ldg) : nullptr;
+    const float4* gt = a.gate ? reinterpret_cast<const float4*>(a.gate + mrow * a.ldg) : nullptr;
     const float4* rs = a.res ? reinterpret_cast<const float4*>(a.res + (int64_t)row * a.ldr) : nullptr;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {

@@ -14,6 +14,7 @@ does not accept them, so that branch cannot run there and no reference output pi
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Optional
 
@@ -240,9 +241,16 @@ class DiffusionWrapper(nn.Module):
             raise NotImplementedError("get_inter is not supported")
         seq_len = self.predict_range if self.predict_range is not None else state.shape[-2]
         B = batch_size * mc_num
+        group = 1
         if mc_num > 1:
             determin_eff = False
-            state = torch.repeat_interleave(state, mc_num, dim=0)
+            # The reference repeats the state mc_num times (diffusion_decoder.py:408-416).  The DiT engine takes the sample
+            # group instead and runs everything that depends on the conditioning alone once per scenario -- same results;
+            # ADX_DIT_GROUP=0 (read per call) or the MM-DiT backbone keep the repeated form.
+            if self.model.config.diffusion_backbone == "DiT" and os.environ.get("ADX_DIT_GROUP", "1") != "0":
+                group = mc_num
+            else:
+                state = torch.repeat_interleave(state, mc_num, dim=0)
         else:
             determin_eff = determin
         eng = self.model.engine()
@@ -261,7 +269,7 @@ class DiffusionWrapper(nn.Module):
                                   device=state.device).reshape(-1, B, seq_len, self.action_dim)
             else:
                 eng.seed_from_torch(seed, row0)
-        out = eng.sample_dit(_lib.f32c(state), _lib.f32c(noise) if noise is not None else None, flags)
+        out = eng.sample_dit(_lib.f32c(state), _lib.f32c(noise) if noise is not None else None, flags, group=group)
         if mc_num > 1:
             out = out.reshape(batch_size, mc_num, *out.shape[1:])
         if not return_scores:

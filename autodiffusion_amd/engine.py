@@ -139,10 +139,18 @@ class Engine:
         check(self.lib.adx_engine_profile_read(self.h, int(stage), C.byref(ms), C.byref(n)), "adx_engine_profile_read")
         return ms.value, n.value
 
-    def sample_dit(self, state, noise, flags: int, out: Optional[torch.Tensor] = None):
-        B, S = state.shape[0], state.shape[1]
+    def sample_dit(self, state, noise, flags: int, out: Optional[torch.Tensor] = None, group: int = 1):
+        """state (B / group, S, d_model): with group > 1 every state item conditions ``group`` consecutive sample rows."""
+        group = int(group)
+        B, S = state.shape[0] * group, state.shape[1]
         n_noise = 0 if noise is None else noise.shape[0]
+        if noise is not None and noise.shape[1] != B:
+            raise ValueError(f"noise holds {noise.shape[1]} rows, the call samples {B}")
         if out is None:
             out = torch.empty(B, S, self.cfg.in_dim, device=state.device, dtype=torch.float32)
-        check(self.lib.adx_sample_dit(self.h, B, ptr(state), ptr(noise), n_noise, ptr(out), flags, current_stream()), "adx_sample_dit")
+        if group == 1:
+            check(self.lib.adx_sample_dit(self.h, B, ptr(state), ptr(noise), n_noise, ptr(out), flags, current_stream()), "adx_sample_dit")
+        else:
+            check(self.lib.adx_sample_dit_grouped(self.h, B, group, ptr(state), ptr(noise), n_noise, ptr(out), flags, current_stream()),
+                  "adx_sample_dit_grouped")
         return out

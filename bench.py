@@ -141,22 +141,26 @@ def dit_macs_per_step(d, L, S=80):
 
 
 def bench_dit(args, dev):
-    """DiffusionDecoder.generate with stochastic sampling (determin=False): B trajectories x N DDPM steps per pass."""
+    """DiffusionDecoder.generate with stochastic sampling (determin=False): B trajectories x N DDPM steps per pass.
+    --mc-num m: the B trajectories are m samples of each of B / m scenarios (the reference's mc_num)."""
     from autodiffusion_amd import dit, ops, synth
     backbone, d, L, h, n_steps, b_def = DIT_WORKLOADS[args.workload]
     n_steps = args.dit_steps or n_steps
     B = args.batch or b_def
-    cfg = dit.dit_config(d, L, h, backbone, k=1, mc_num=1, diffusion_timesteps=n_steps, precision=args.precision)
+    mc = max(args.mc_num, 1)
+    if B % mc:
+        raise SystemExit("--batch must be a multiple of --mc-num")
+    cfg = dit.dit_config(d, L, h, backbone, k=mc, mc_num=mc, diffusion_timesteps=n_steps, precision=args.precision)
     dec = dit.DiffusionDecoder(cfg).to(dev).eval()
     torch.manual_seed(11)
     with torch.no_grad():
         for p in dec.parameters():          # every tensor N(0, 0.02): the reference zero-inits adaLN, which would idle the blocks
             p.normal_(0.0, 0.02)
-    state = synth.hidden_state(B, cfg.n_embd, 7).to(dev)
+    state = synth.hidden_state(B // mc, cfg.n_embd, 7).to(dev)
     noise = synth.noise(B, (n_steps + 1,), (80, 4), 1234).to(dev)
 
     def step():
-        return dec.model(state, batch_size=B, determin=False, noise=noise)
+        return dec.model(state, batch_size=B // mc, determin=False, noise=noise, mc_num=mc)
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
@@ -179,7 +183,7 @@ def bench_dit(args, dev):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "fp32" if args.precision == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": f"{backbone} decoder d={d} L={L} h={h}, {n_steps} DDPM steps (cosine), stochastic sampling, random init, "
-                               "synthetic backbone hidden states", "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
+                               "synthetic backbone hidden states" + (f", {mc} samples per scenario" if mc > 1 else ""), "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
                    "precision": args.precision, "dense_tflops_whole_pass": round(flops / dt / 1e12, 2)},
         "roofline": {"kernel": f"linear_kernel M={M} N={N} K={K}", "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -312,6 +316,7 @@ def main():
     ap.add_argument("--frame-stack", type=int, default=0, help="refiner: points per chunk (default 10; 80 = whole trajectory)")
     ap.add_argument("--n-train", type=int, default=0, help="refiner: training timesteps (default 100)")
     ap.add_argument("--n-sample", type=int, default=0, help="refiner: sampling steps (default 50; equal to --n-train = DDPM loop)")
+    ap.add_argument("--mc-num", type=int, default=1, help="DiT workloads: samples per scenario (--batch counts trajectories)")
     ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
