@@ -275,11 +275,16 @@ struct EngineDiT final : adx_engine {
         } else {
             const int kd = d;                   // k_dim = v_dim = d_model per head, per stream
             const int hd = 2 * kd;              // joint head width (x part then c part)
-            ADX_HIP(copy2d(SE, d, 0, CC, d, R, d, s));
+            // the condition stream starts from the state embedding of the sample's scenario (it then evolves per sample; only the
+            // modulation tables, functions of the conditioning alone, stay shared inside a sample group)
+            if (group == 1) ADX_HIP(copy2d(SE, d, 0, CC, d, R, d, s));
+            else
+                for (int g = 0; g < group; ++g)     // item b G + g <- item b: whole items as rows of S d floats
+                    ADX_HIP(copy2d(SE, (int64_t)S * d, 0, CC + (size_t)g * S * d, (int64_t)group * S * d, B / group, S * d, s));
             for (int i = 0; i < NL; ++i) {
                 const std::string p = "blocks." + std::to_string(i);
-                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation_x.1.weight", 0, 6 * d, d, p + ".adaLN_modulation_x.1.bias", MOD, 6 * d, R), s));
-                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation_c.1.weight", 0, 6 * d, d, p + ".adaLN_modulation_c.1.bias", MODC, 6 * d, R), s));
+                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation_x.1.weight", 0, 6 * d, d, p + ".adaLN_modulation_x.1.bias", MOD, 6 * d, Rc), s));
+                ADX_HIP(linear(lin(SIL, d, p + ".adaLN_modulation_c.1.weight", 0, 6 * d, d, p + ".adaLN_modulation_c.1.bias", MODC, 6 * d, Rc), s));
                 ADX_TRY(ln_mod(HX, HN, MOD, 6 * d, 0, R, s));
                 ADX_TRY(ln_mod(CC, HN2, MODC, 6 * d, 0, R, s));
                 const char* names[3] = {"Wq_", "Wk_", "Wv_"};
@@ -306,12 +311,14 @@ struct EngineDiT final : adx_engine {
                     float* hn = st ? HN2 : HN;
                     LinearArgs l1 = lin(OB, d, p + ".linear_" + q + ".0.weight", 0, d, d, p + ".linear_" + q + ".0.bias", attn_buf, d, R, ACT_GELU_TANH);
                     l1.gate = mod + 2 * d; l1.ldg = 6 * d; l1.res = stream_buf; l1.ldr = d;
+                    l1.gate_group = mod_group(); l1.gate_period = S;
                     ADX_HIP(linear(l1, s));
                     ADX_TRY(ln_mod(attn_buf, hn, mod, 6 * d, 3, R, s));
                     ADX_HIP(linear(lin(hn, d, p + ".mlp_" + q + ".0.weight", 0, 4 * d, d, p + ".mlp_" + q + ".0.bias", FF, 4 * d, R, ACT_GELU_TANH), s));
                     // residual from the stream's block INPUT, not from attn_buf
                     LinearArgs m2 = lin(FF, 4 * d, p + ".mlp_" + q + ".2.weight", 0, d, 4 * d, p + ".mlp_" + q + ".2.bias", stream_buf, d, R, ACT_GELU_TANH);
                     m2.gate = mod + 5 * d; m2.ldg = 6 * d; m2.res = stream_buf; m2.ldr = d;
+                    m2.gate_group = mod_group(); m2.gate_period = S;
                     ADX_HIP(linear(m2, s));
                 }
             }
@@ -342,7 +349,6 @@ struct EngineDiT final : adx_engine {
     int sample(int B, const float* state, const float* noise, int n_noise, float* out, unsigned flags, hipStream_t s, int G = 1) {
         ADX_TRY(check_ready(B, "sample_dit"));
         if (G < 1 || B % G != 0) { set_error("sample_dit: the batch must be a multiple of the sample group"); return ADX_EINVAL; }
-        if (G > 1 && mm) { set_error("sample_dit: sample groups need the DiT backbone (the MM-DiT conditioning stream depends on the sample)"); return ADX_EINVAL; }
         if (steps.empty()) { set_error("sample_dit: no schedule set"); return ADX_ESTATE; }
         if (cfg.in_dim != cfg.out_dim) { set_error("sample_dit: in_dim must equal out_dim"); return ADX_EINVAL; }
         const int64_t n = (int64_t)B * S * C;

@@ -244,10 +244,10 @@ class DiffusionWrapper(nn.Module):
         group = 1
         if mc_num > 1:
             determin_eff = False
-            # The reference repeats the state mc_num times (diffusion_decoder.py:408-416).  The DiT engine takes the sample
-            # group instead and runs everything that depends on the conditioning alone once per scenario -- same results;
-            # ADX_DIT_GROUP=0 (read per call) or the MM-DiT backbone keep the repeated form.
-            if self.model.config.diffusion_backbone == "DiT" and os.environ.get("ADX_DIT_GROUP", "1") != "0":
+            # The reference repeats the state mc_num times (diffusion_decoder.py:408-416).  The engine takes the sample group
+            # instead and runs everything that depends on the conditioning alone once per scenario -- same results;
+            # ADX_DIT_GROUP=0 (read per call) keeps the repeated form.
+            if os.environ.get("ADX_DIT_GROUP", "1") != "0":
                 group = mc_num
             else:
                 state = torch.repeat_interleave(state, mc_num, dim=0)

@@ -140,6 +140,14 @@ def dit_macs_per_step(d, L, S=80):
     return L * (26 * S * d * d + 2 * S * S * d) + S * x_enc + (2 * S * d * d + 4 * S * d) + 8 * d * d
 
 
+def mmdit_macs_per_step(d, L, h, S=80):
+    """The same count for the MM-DiT backbone: per block the q/k/v maps of both streams (6 S d^2 h), joint attention over
+    head width 2 d (4 S^2 d h), its projection (2 S d^2 h), both modulations (12 S d^2), linear_x/c (2 S d^2), both MLPs (16 S d^2)."""
+    x_enc = 1942272 + 768 * 2048 + 2816 * d
+    block = 8 * S * d * d * h + 4 * S * S * d * h + 30 * S * d * d
+    return L * block + S * x_enc + (2 * S * d * d + 4 * S * d) + 8 * d * d
+
+
 def bench_dit(args, dev):
     """DiffusionDecoder.generate with stochastic sampling (determin=False): B trajectories x N DDPM steps per pass.
     --mc-num m: the B trajectories are m samples of each of B / m scenarios (the reference's mc_num)."""
@@ -177,7 +185,7 @@ def bench_dit(args, dev):
     bias = torch.zeros(N, device=dev)
     tg = time_kernel(lambda k: [ops.linear(x, w, bias, precision=args.precision, prepared_n=N) for _ in range(k)], 10)
     achieved = 2.0 * M * N * K / tg / 1e12
-    flops = 2.0 * dit_macs_per_step(d, L) * B * n_steps
+    flops = 2.0 * (dit_macs_per_step(d, L) if backbone == "DiT" else mmdit_macs_per_step(d, L, h)) * B * n_steps
     line = {
         "metric": "denoised trajectories/sec (8s, 80-pt)", "value": round(B / dt, 2), "unit": "trajectories/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",

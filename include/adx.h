@@ -260,9 +260,9 @@ int adx_sample_dit(adx_engine* e, int B, const float* state, const float* noise,
 /* The same loop for mc_num samples per scenario -- diffusion_decoder.py:408-416 repeats every scenario's state mc_num times
  * (repeat_interleave) before sampling.  Here the B sample rows come in groups of `group` consecutive rows that share one
  * state item: state[B / group][S][d_model], everything else as adx_sample_dit (noise and out have B rows).  The state
- * encoder and every adaLN modulation run once per scenario instead of once per sample; results are those of
- * adx_sample_dit on the repeated state.  DiT backbone only (ADX_EINVAL for MM-DiT, whose conditioning stream evolves with
- * the sample); B must be a multiple of group. */
+ * encoder and every adaLN modulation run once per scenario instead of once per sample (MM-DiT: its condition stream
+ * evolves with the sample and stays per sample; the modulation tables of both streams are shared); results are those of
+ * adx_sample_dit on the repeated state.  B must be a multiple of group. */
 int adx_sample_dit_grouped(adx_engine* e, int B, int group, const float* state, const float* noise, int n_noise,
                            float* out, unsigned flags, void* stream);
 

@@ -918,14 +918,16 @@ def test_config_c4_sixteen_samples(dev, golden, backbone):
             assert modes.shape == (1, 6, 80, 4) and bool(torch.isfinite(modes).all())
 
 
+@pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
 @pytest.mark.parametrize("prec,scen,mc,tol", [("fp32", 3, 4, 2e-6), ("fp32", 48, 16, 2e-6), ("bf16x3", 48, 16, 1e-5), ("bf16", 48, 16, 2e-2)])
-def test_sample_group_equals_repeated_state(dev, monkeypatch, prec, scen, mc, tol):
+def test_sample_group_equals_repeated_state(dev, monkeypatch, backbone, prec, scen, mc, tol):
     """mc_num samples per scenario: the engine's sample group (state given once per scenario, conditioning-only work done once
     per scenario) against the reference's form, the state repeated mc_num times (diffusion_decoder.py:408-416).  The two differ
     only in the row count of the modulation products, i.e. at most in which kernel takes them; 48 x 16 x 80 = 61440 token rows
-    send the block products to the staged kernel and the modulation products (3840 rows) to operand planes."""
+    send the block products to the staged kernel and the modulation products (3840 rows) to operand planes.  MM-DiT shares the
+    modulation tables of both streams; its condition stream evolves per sample and starts from the scenario's state embedding."""
     from autodiffusion_amd import dit, synth, _lib
-    dec = dit.DiffusionDecoder(dit.dit_config(256, 2, 8, "DiT", k=mc, mc_num=mc, diffusion_timesteps=10, precision=prec))
+    dec = dit.DiffusionDecoder(dit.dit_config(256, 2, 8, backbone, k=mc, mc_num=mc, diffusion_timesteps=10, precision=prec))
     torch.manual_seed(13)
     with torch.no_grad():                       # N(0, 0.02): trajectories stay off the +-100 clamp, so differences would show
         for p in dec.parameters():
@@ -938,20 +940,15 @@ def test_sample_group_equals_repeated_state(dev, monkeypatch, prec, scen, mc, to
     repeated = dec.generate(state, noise=noise)
     assert grouped.shape == repeated.shape == (scen, mc, 80, 4)
     e = rel_err(grouped.cpu(), repeated.cpu())
-    print(f"sample group {scen}x{mc} {prec}: rel diff {e:.2e}")
+    print(f"sample group {backbone} {scen}x{mc} {prec}: rel diff {e:.2e}")
     assert e < tol
     # the samples of one scenario must differ (their noise does), scenarios too
     assert float((grouped[:, 0] - grouped[:, 1]).abs().max()) > 0 and float((grouped[0] - grouped[1]).abs().max()) > 0
-    # argument checks of the entry point: a batch that is no multiple of the group; the MM-DiT backbone
+    # argument check of the entry point: a batch that is no multiple of the group
     eng = dec.model.model.engine()
     with pytest.raises(_lib.AdxError):
         _lib.check(eng.lib.adx_sample_dit_grouped(eng.h, scen * mc - 1, mc, _lib.ptr(state), None, 0, _lib.ptr(grouped),
                                                   _lib.FLAG_INIT_ZERO, None), "adx_sample_dit_grouped")
-    if prec == "fp32" and scen == 3:
-        mm = dit.DiffusionDecoder(dit.dit_config(256, 1, 8, "MM-DiT", k=mc, mc_num=mc, diffusion_timesteps=10, precision=prec)).to(dev).eval()
-        assert mm.generate(state, noise=noise).shape == (scen, mc, 80, 4)          # falls back to the repeated state
-        with pytest.raises(_lib.AdxError):
-            mm.model.model.engine().sample_dit(state, noise, 0, group=mc)
 
 
 @pytest.mark.parametrize("backbone,L", [("DiT", 2), ("MM-DiT", 1)])
