@@ -145,14 +145,34 @@ struct EngineDiT final : adx_engine {
 
     // chain of residual-concat stages; input already sits in cat[0][:, :in0]; last fc writes `out` (+ pos)
     // Stages whose input is raw trajectory coordinates (in <= 8 channels) always run in fp32.
+    // A stage both of whose products the staged GEMM takes keeps its concatenated input [x | relu(LN(Linear x))] as operand
+    // planes ONLY, in the bytes of the fp32 buffer (two bf16 planes = one float per element; K-blocked planes concatenate
+    // along K by appending blocks): the previous stage's fc and the stage's own LayerNorm write them, no re-layout pass runs
+    // and the fp32 concatenation never exists.
     int run_stages(const std::vector<Stage>& st, std::vector<float*>& cat, int R, float* out, const float* pos, hipStream_t s) {
+        const int eprec = cfg.precision;
+        const bool x3 = eprec == ADX_PREC_BF16X3;
+        const char* pl_env = getenv("ADX_DIT_PLANES");               // read per call: 0 = fp32 activations between all kernels
+        const char* st_env = getenv("ADX_DIT_STAGE_PLANES");         // 0 = only these stages keep fp32 concatenations (A/B switch)
+        const bool planes_on = eprec != ADX_PREC_F32 && !(pl_env && pl_env[0] == '0') && !(st_env && st_env[0] == '0');
+        auto as_planes = [&](size_t i) {
+            const Stage& g = st[i];
+            return planes_on && i > 0 /* the chain's input arrives as fp32 */ && g.in > 8 && (g.in % 16) == 0 && (g.hidden % 256) == 0 && (g.out % 16) == 0 &&
+                   linear_planes_ok(R, g.hidden, g.in, eprec) && linear_planes_ok(R, g.out, g.in + g.hidden, eprec);
+        };
         for (size_t i = 0; i < st.size(); ++i) {
             const Stage& g = st[i];
             const int ld = g.in + g.hidden;
             const int prec = g.in <= 8 ? (int)PREC_F32 : -1;
-            ADX_HIP(linear(lin(cat[i], ld, g.name + ".mlp.linear.weight", 0, g.hidden, g.in, g.name + ".mlp.linear.bias", HT, g.hidden, R, ACT_NONE, prec), s));
+            const bool pk = as_planes(i);
+            unsigned short* ph = reinterpret_cast<unsigned short*>(cat[i]);
+            unsigned short* pl = x3 ? ph + (size_t)R * ld : nullptr;
+            LinearArgs l1 = lin(cat[i], ld, g.name + ".mlp.linear.weight", 0, g.hidden, g.in, g.name + ".mlp.linear.bias", HT, g.hidden, R, ACT_NONE, prec);
+            if (pk) { l1.Xh = ph; l1.Xl = pl; }                       // the first in/16 blocks of the stage's planes
+            ADX_HIP(linear(l1, s));
             LayerNormArgs ln;
             ln.x = HT; ln.ldx = g.hidden; ln.y = cat[i] + g.in; ln.ldy = ld;
+            if (pk) { ln.y = nullptr; ln.ph = ph + (size_t)g.in * R; ln.pl = x3 ? pl + (size_t)g.in * R : nullptr; }
             ln.gamma = P(g.name + ".mlp.layer_norm.weight"); ln.beta = P(g.name + ".mlp.layer_norm.bias");
             ln.eps = 1e-5f; ln.rows = R; ln.d = g.hidden; ln.relu = 1;
             ADX_HIP(layernorm(ln, s));
@@ -160,6 +180,12 @@ struct EngineDiT final : adx_engine {
             float* y = lastst ? out : cat[i + 1];
             const int ldy = lastst ? g.out : st[i + 1].in + st[i + 1].hidden;
             LinearArgs fc = lin(cat[i], ld, g.name + ".fc.weight", 0, g.out, ld, g.name + ".fc.bias", y, ldy, R, ACT_NONE, prec);
+            if (pk) { fc.Xh = ph; fc.Xl = pl; }
+            if (!lastst && as_planes(i + 1)) {
+                fc.Y = nullptr;
+                fc.Yh = reinterpret_cast<unsigned short*>(cat[i + 1]);
+                fc.Yl = x3 ? fc.Yh + (size_t)R * ldy : nullptr;
+            }
             if (lastst && pos) { fc.pos = pos; fc.ldp = g.out; fc.pos_period = S; fc.pos_off = 0; }
             ADX_HIP(linear(fc, s));
         }

@@ -363,6 +363,70 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs 
     }
 }
 
+// The form for results that go out as operand planes [d/16][rows][16]: a QUARTER wave (16 lanes) per row, a wave takes four
+// consecutive rows, a lane keeps NQ = d/64 float4 of its row.  The four lanes that share a 16-column block of a row write its
+// 32 bytes, and the four quarters write four consecutive rows of that block: one store instruction covers whole 128-byte
+// lines (with a wave per row the same instruction touched sixteen 32-byte pieces a whole plane block apart, and the kernel
+// ran at half the rate of the fp32 store).
+template <int NQ>
+__global__ __launch_bounds__(256) void layernorm_planes_kernel(const LayerNormArgs a) {
+    const int lane = threadIdx.x & 63, ql = lane & 15;
+    const int row_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row_raw < a.rows;
+    const int row = live ? row_raw : a.rows - 1;
+    const float4* x = reinterpret_cast<const float4*>(a.x + map_row(a.xmap, row) * a.ldx);
+    float4 v[NQ];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { v[i] = x[ql + 16 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    auto quarter_sum = [](float t) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    const float inv_d = 1.0f / (64.0f * NQ);
+    const float mean = quarter_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = rsqrt_fast(quarter_sum(q) * inv_d + a.eps);
+    const int64_t mrow = a.mod_group ? (int64_t)(row / a.mod_group) * a.mod_period + row % a.mod_period : (int64_t)row;
+    const float4* sh = a.shift ? reinterpret_cast<const float4*>(a.shift + mrow * a.ldm) : nullptr;
+    const float4* sc = a.scale ? reinterpret_cast<const float4*>(a.scale + mrow * a.ldm) : nullptr;
+    const float4* ga = reinterpret_cast<const float4*>(a.gamma);
+    const float4* be = reinterpret_cast<const float4*>(a.beta);
+    const float4* gt = a.gate ? reinterpret_cast<const float4*>(a.gate + mrow * a.ldg) : nullptr;
+    const float4* rs = a.res ? reinterpret_cast<const float4*>(a.res + (int64_t)row * a.ldr) : nullptr;
+    float4* y = a.y ? reinterpret_cast<float4*>(a.y + (int64_t)row * a.ldy) : nullptr;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int c = ql + 16 * i;                  // float4 index in the row: columns 4c .. 4c+3, block c >> 2
+        float o[4] = {v[i].x * rstd, v[i].y * rstd, v[i].z * rstd, v[i].w * rstd};
+        if (ga) { const float4 g = ga[c], b = be[c]; o[0] = fmaf(o[0], g.x, b.x); o[1] = fmaf(o[1], g.y, b.y); o[2] = fmaf(o[2], g.z, b.z); o[3] = fmaf(o[3], g.w, b.w); }
+        if (sc) { const float4 k = sc[c], h = sh[c]; o[0] = fmaf(o[0], 1.f + k.x, h.x); o[1] = fmaf(o[1], 1.f + k.y, h.y); o[2] = fmaf(o[2], 1.f + k.z, h.z); o[3] = fmaf(o[3], 1.f + k.w, h.w); }
+        if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        if (gt) { const float4 g = gt[c]; o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
+        if (rs) { const float4 r = rs[c]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+        if (!live) continue;
+        if (y) y[c] = make_float4(o[0], o[1], o[2], o[3]);
+        const int64_t off = ((int64_t)(c >> 2) * a.rows + row) * 16 + ((4 * c) & 15);
+        bf16x4_t hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = (__bf16)o[e];
+        *reinterpret_cast<bf16x4_t*>(a.ph + off) = hi;
+        if (a.pl) {
+            bf16x4_t lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(o[e] - (float)hi[e]);
+            *reinterpret_cast<bf16x4_t*>(a.pl + off) = lo;
+        }
+    }
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
@@ -374,6 +438,20 @@ hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
     const dim3 grid((a.rows + 3) / 4), block(256);
     if (a.ph && (!vec || a.ymap.per_batch != 0)) return hipErrorInvalidValue;       // planes come from the register-resident kernel only
     if (!a.y && !a.ph) return hipErrorInvalidValue;
+    if (vec && a.ph && a.ymap.per_batch == 0) {     // planes: the quarter-wave form (rows up to 2048 floats keep a lane within 32 float4)
+        const char* e = getenv("ADX_LN_PLANES_ROWWAVE");        // measurement switch, read per call: 1 = the wave-per-row form below
+        if (!(e && e[0] == '1')) {
+            const dim3 qgrid((a.rows + 15) / 16);
+            switch (a.d / 64) {
+                case 4: hipLaunchKernelGGL(layernorm_planes_kernel<4>, qgrid, block, 0, stream, a); return hipGetLastError();
+                case 8: hipLaunchKernelGGL(layernorm_planes_kernel<8>, qgrid, block, 0, stream, a); return hipGetLastError();
+                case 12: hipLaunchKernelGGL(layernorm_planes_kernel<12>, qgrid, block, 0, stream, a); return hipGetLastError();
+                case 16: hipLaunchKernelGGL(layernorm_planes_kernel<16>, qgrid, block, 0, stream, a); return hipGetLastError();
+                case 32: hipLaunchKernelGGL(layernorm_planes_kernel<32>, qgrid, block, 0, stream, a); return hipGetLastError();
+                default: break;
+            }
+        }
+    }
     if (vec) {
         switch (a.d / 256) {
             case 1: hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, block, 0, stream, a); return hipGetLastError();

@@ -193,6 +193,30 @@ def test_dit_row_stationary_gemm(dev, d, h, backbone):
     assert e < 1e-4
 
 
+@pytest.mark.parametrize("backbone,prec", [("DiT", "bf16x3"), ("DiT", "bf16"), ("MM-DiT", "bf16x3")])
+def test_dit_encoder_stage_planes(dev, monkeypatch, backbone, prec):
+    """B = 640 (51200 token rows): the wide stages of the trajectory encoder (512 -> 1024 -> 768 and 768 -> 2048 -> d) keep
+    their concatenated inputs as bf16 operand planes only.  The first items against the CPU oracle (a row's result does not
+    depend on the batch), the whole batch against the same call with fp32 activations between all kernels."""
+    from autodiffusion_amd import dit, synth
+    from oracle import nets
+    B, d, h = 640, 256, 8
+    m = dit.Transformer_TrajDiffusionModel(dit.dit_config(d, 1, h, backbone, precision=prec))
+    synth.fill_module_(m, WSEED)
+    sd = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+    m = m.to(dev).eval()
+    x, state = synth.noise(B, (), (80, 4), NSEED), synth.hidden_state(B, d, ISEED)
+    t = torch.arange(B, dtype=torch.long) * 3 % 10
+    ref = nets.dit_forward(sd, x[:3], t[:3], state[:3], h, backbone)
+    out = m(x.to(dev), t.to(dev), state.to(dev)).cpu()
+    monkeypatch.setenv("ADX_DIT_PLANES", "0")
+    plain = m(x.to(dev), t.to(dev), state.to(dev)).cpu()
+    e, e0, ep = rel_err(out[:3], ref), rel_err(plain[:3], ref), rel_err(out, plain)
+    print(f"{backbone} {prec} stage planes: rel err {e:.2e} (fp32 activations: {e0:.2e}); planes vs fp32 activations {ep:.2e}")
+    tol = 1e-4 if prec == "bf16x3" else 3e-2
+    assert e < tol and e0 < tol and ep < tol      # (the two forms may agree to the bit: same split, same k order)
+
+
 def test_op_linear_asymmetric_identity(dev):
     """A = I against an asymmetric W catches a transposed accumulator layout."""
     from autodiffusion_amd import ops
