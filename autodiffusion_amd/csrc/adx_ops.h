@@ -57,6 +57,11 @@ hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, u
 size_t linear_stage_bytes(int M, int N, int K, int prec);
 hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream);   // [N][K] bf16 -> [K/16][N][16]
 hipError_t linear(const LinearArgs& a, hipStream_t stream);        // picks linear_big when linear_big_ok(a)
+// Two products in one kernel, the hidden layer kept on the chip: Y = epilogue2(act1(X W1^T + b1) W2^T + b2) for K = 256 inputs and
+// 256 outputs (gemm.hip).  l1 carries X, the first weight (K-blocked copies required), bias and activation; l2 the second
+// weight and the whole epilogue (bias, activation, gate, residual, Y and / or plane outputs); l1.Y and l2.X are not used.
+bool mlp256_ok(const LinearArgs& l1, const LinearArgs& l2);
+hipError_t mlp256(const LinearArgs& l1, const LinearArgs& l2, hipStream_t stream);
 bool linear_big_ok(const LinearArgs& a);                             // large-tile bf16 kernel (gemm.hip) applies
 hipError_t linear_big(const LinearArgs& a, hipStream_t stream);
 

@@ -393,6 +393,27 @@ ADX_API int adx_op_linear_planes(const void* x_planes, const void* w_blocked, co
     return done(linear(a, (hipStream_t)stream), "linear_planes");
 }
 
+ADX_API int adx_op_mlp256(const float* x, const void* w1_blocked, const float* b1, int act1, const void* w2_blocked, const float* b2, int act2,
+                          const float* gate, const float* res, float* y, int M, int N1, int prec, void* stream) {
+    if (!x || !w1_blocked || !w2_blocked || !y) return fail(ADX_EINVAL, "mlp256: null pointer");
+    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "mlp256: bf16 precisions only");
+    if (M <= 0 || N1 <= 0) return fail(ADX_EINVAL, "mlp256: empty shape");
+    const int D = 256;
+    LinearArgs l1, l2;
+    const uint16_t* w1 = reinterpret_cast<const uint16_t*>(w1_blocked);
+    const uint16_t* w2 = reinterpret_cast<const uint16_t*>(w2_blocked);
+    l1.X = x; l1.ldx = D; l1.W = w1; l1.Wblk = w1; l1.bias = b1; l1.act = act1; l1.M = M; l1.N = N1; l1.K = D; l1.prec = prec;
+    l2.W = w2; l2.Wblk = w2; l2.bias = b2; l2.act = act2; l2.M = M; l2.N = D; l2.K = N1; l2.prec = prec;
+    l2.gate = gate; l2.ldg = D; l2.res = res; l2.ldr = D; l2.Y = y; l2.ldy = D;
+    if (prec == ADX_PREC_BF16X3) {
+        l1.Wblk_lo = w1 + (size_t)N1 * D; l1.Wlo = l1.Wblk_lo;
+        l2.Wblk_lo = w2 + (size_t)N1 * D; l2.Wlo = l2.Wblk_lo;
+    }
+    if (!mlp256_ok(l1, l2))
+        return fail(ADX_EINVAL, "mlp256: needs M >= 128, a hidden width that is a multiple of 64 (at most 4096) and 16-byte aligned operands");
+    return done(mlp256(l1, l2, (hipStream_t)stream), "mlp256");
+}
+
 ADX_API int adx_op_select_modes(const float* traj, int B, int M, int L, int D, int k, int em_iter, float* modes, float* weights,
                                 void* stream) {
     if (!traj || !modes || !weights) return fail(ADX_EINVAL, "select_modes: null pointer");

@@ -241,6 +241,9 @@ struct EngineDiT final : adx_engine {
         ADX_TRY(run_stages(x_stages, x_cat, R, HX, P("position_embedding"), s));
         // SiLU(t_emb + state_emb): the only use of the conditioning sum is through SiLU (adaLN inputs)
         ADX_HIP(add_vec_act(SE, te, SIL, Rc, d, rows_per_vec, ACT_SILU, s));
+        // hidden size 256: the two-layer MLPs of a block run as one kernel each, their 4d-wide hidden layers stay on the chip
+        const char* fm_env = getenv("ADX_DIT_FUSED_MLP");              // read per call: 0 = two products through memory
+        const bool fuse_mlp = d == 256 && cfg.precision != ADX_PREC_F32 && R >= 4096 && !(fm_env && fm_env[0] == '0');
         if (!mm) {
             const int dh = d / H;
             // Operand planes: where the staged GEMM will take a product (enough tiles, long enough K), the kernel that PRODUCES
@@ -277,26 +280,32 @@ struct EngineDiT final : adx_engine {
                 ADX_HIP(linear(o, s));
                 ADX_TRY(ln_affine(Z0, Z1, p + ".attn.norm1", R, nullptr, 0, nullptr, s, pk_d ? Z1P : nullptr));
                 LinearArgs f1 = lin(Z1, d, p + ".attn.linear1.weight", 0, 4 * d, d, p + ".attn.linear1.bias", FF, 4 * d, R, ACT_RELU);
-                if (pk_d) use_planes(f1, Z1P, d);
-                if (pk_4d) out_planes(f1, FFP, 4 * d);
-                ADX_HIP(linear(f1, s));
                 LinearArgs f2 = lin(FF, 4 * d, p + ".attn.linear2.weight", 0, d, 4 * d, p + ".attn.linear2.bias", Z0, d, R);
-                if (pk_4d) use_planes(f2, FFP, 4 * d);
                 f2.res = Z1; f2.ldr = d;
-                ADX_HIP(linear(f2, s));
+                if (fuse_mlp && mlp256_ok(f1, f2)) {
+                    ADX_HIP(mlp256(f1, f2, s));
+                } else {
+                    if (pk_d) use_planes(f1, Z1P, d);
+                    if (pk_4d) { out_planes(f1, FFP, 4 * d); use_planes(f2, FFP, 4 * d); }
+                    ADX_HIP(linear(f1, s));
+                    ADX_HIP(linear(f2, s));
+                }
                 // x = x + gate_msa * norm2(...)
                 ADX_TRY(ln_affine(Z0, HX, p + ".attn.norm2", R, MOD + 2 * d, 6 * d, HX, s));
                 // x = x + gate_mlp * gelu(W2 gelu(W1 modulate(LN(x))))
-                ADX_TRY(ln_mod(HX, pk_d ? nullptr : HN, MOD, 6 * d, 3, R, s, pk_d ? HNP : nullptr));
+                ADX_TRY(ln_mod(HX, (pk_d && !fuse_mlp) ? nullptr : HN, MOD, 6 * d, 3, R, s, pk_d ? HNP : nullptr));
                 LinearArgs m1 = lin(HN, d, p + ".mlp.0.weight", 0, 4 * d, d, p + ".mlp.0.bias", FF, 4 * d, R, ACT_GELU_TANH);
-                if (pk_d) use_planes(m1, HNP, d);
-                if (pk_4d) out_planes(m1, FFP, 4 * d);
-                ADX_HIP(linear(m1, s));
                 LinearArgs m2 = lin(FF, 4 * d, p + ".mlp.2.weight", 0, d, 4 * d, p + ".mlp.2.bias", HX, d, R, ACT_GELU_TANH);
-                if (pk_4d) use_planes(m2, FFP, 4 * d);
                 m2.gate = MOD + 5 * d; m2.ldg = 6 * d; m2.res = HX; m2.ldr = d;
                 m2.gate_group = mod_group(); m2.gate_period = S;
-                ADX_HIP(linear(m2, s));
+                if (fuse_mlp && mlp256_ok(m1, m2)) {
+                    ADX_HIP(mlp256(m1, m2, s));
+                } else {
+                    if (pk_d) use_planes(m1, HNP, d);
+                    if (pk_4d) { out_planes(m1, FFP, 4 * d); use_planes(m2, FFP, 4 * d); }
+                    ADX_HIP(linear(m1, s));
+                    ADX_HIP(linear(m2, s));
+                }
             }
         } else {
             const int kd = d;                   // k_dim = v_dim = d_model per head, per stream
@@ -340,12 +349,17 @@ struct EngineDiT final : adx_engine {
                     l1.gate_group = mod_group(); l1.gate_period = S;
                     ADX_HIP(linear(l1, s));
                     ADX_TRY(ln_mod(attn_buf, hn, mod, 6 * d, 3, R, s));
-                    ADX_HIP(linear(lin(hn, d, p + ".mlp_" + q + ".0.weight", 0, 4 * d, d, p + ".mlp_" + q + ".0.bias", FF, 4 * d, R, ACT_GELU_TANH), s));
+                    LinearArgs m1 = lin(hn, d, p + ".mlp_" + q + ".0.weight", 0, 4 * d, d, p + ".mlp_" + q + ".0.bias", FF, 4 * d, R, ACT_GELU_TANH);
                     // residual from the stream's block INPUT, not from attn_buf
                     LinearArgs m2 = lin(FF, 4 * d, p + ".mlp_" + q + ".2.weight", 0, d, 4 * d, p + ".mlp_" + q + ".2.bias", stream_buf, d, R, ACT_GELU_TANH);
                     m2.gate = mod + 5 * d; m2.ldg = 6 * d; m2.res = stream_buf; m2.ldr = d;
                     m2.gate_group = mod_group(); m2.gate_period = S;
-                    ADX_HIP(linear(m2, s));
+                    if (fuse_mlp && mlp256_ok(m1, m2)) {
+                        ADX_HIP(mlp256(m1, m2, s));
+                    } else {
+                        ADX_HIP(linear(m1, s));
+                        ADX_HIP(linear(m2, s));
+                    }
                 }
             }
         }

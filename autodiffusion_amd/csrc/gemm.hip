@@ -1295,6 +1295,287 @@ static hipError_t launch_rows(const LinearArgs& a, hipStream_t stream) {
     }
 }
 
+// ============================================================================================================
+// Two-layer MLP of width 256 in one kernel: Y = epilogue2(act1(X W1^T + b1) W2^T + b2), X [M][256], W1 [N1][256], W2 [256][N1].
+// The hidden layer (4 floats per element and token when it goes through memory as operand planes, written once and read
+// once) never leaves the CU.  A workgroup of four waves -- one per SIMD, up to 512 registers each -- owns 128 rows:
+//   * a wave keeps its 32 rows of X as MFMA fragments (128 VGPRs with split operands) and the 32 x 256 result as eight
+//     accumulators (128 more);
+//   * the hidden layer is walked 64 units at a time.  Phase 1: H^T = W1_tile X^T, two 32-unit tiles with interleaved
+//     accumulation chains (A = W1 rows, B = the X fragments: the accumulator then holds "token on the lane, hidden unit on
+//     the registers", which is the B operand of the next product as it stands).  The rows of a W1 tile are fetched in the
+//     order that makes registers 8u .. 8u+7 of a lane half the k elements 8 half .. 8 half + 7 of k16 step u.
+//     Phase 2: Y^T += W2_chunk H^T over the eight output tiles, independent chains.
+//   * W1 tiles and W2 chunks come from the K-blocked weight copies by LDS-DMA into one 64 KB buffer each; the copies of a
+//     phase's operands are issued during the phase before it, two barriers per 64 hidden units.
+//   * epilogue: the accumulators go through a wave-private LDS patch (in the W1 buffer, free by then) to epilogue_patch, so
+//     bias, activation, gate (with row groups), residual and plane outputs are those of every other product.
+// ============================================================================================================
+constexpr int MLP_D = 256;
+
+__device__ __forceinline__ int mlp_row_perm(int m) { return (m & ~12) | ((m & 4) << 1) | ((m & 8) >> 1); }     // swaps bits 2 and 3
+
+template <bool X3, int ACT1, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, const LinearArgs a2) {
+    constexpr int KS = MLP_D / 16;                            // k16 steps of the first product
+    constexpr int PL = X3 ? 2 : 1;
+    constexpr int W1_TILE_B = KS * 1024;                      // one plane of a 32-unit tile: [k16 step][k half][unit] 16-byte pieces
+    constexpr int W1_BUF_B = 2 * PL * W1_TILE_B;              // two tiles
+    constexpr int W2_PLANE_B = 8 * 4 * 1024;                  // one plane of a 64-unit chunk: [out tile][k16 step][k half][row]
+    constexpr int W2_BUF_B = PL * W2_PLANE_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* w1buf = smem;
+    unsigned char* w2buf = smem + W1_BUF_B;
+    const int M = a1.M, N1 = a1.N;
+    constexpr int EP_B = 4 * 4 * 32 * EP_LD * (int)sizeof(float);       // the epilogue's patches reuse the weight buffers
+    constexpr int BIAS_OFF = W1_BUF_B + W2_BUF_B > EP_B ? W1_BUF_B + W2_BUF_B : EP_B;
+    float* lb1 = reinterpret_cast<float*>(smem + BIAS_OFF);
+    float* lb2 = lb1 + N1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fc = lane >> 5;
+    const int m0 = (int)blockIdx.x * 128 + wave * 32;
+    for (int i = tid; i < N1; i += 256) lb1[i] = a1.bias ? a1.bias[i] : 0.f;
+    for (int i = tid; i < MLP_D; i += 256) lb2[i] = a2.bias ? a2.bias[i] : 0.f;
+
+    const unsigned short* W1h = reinterpret_cast<const unsigned short*>(a1.Wblk);
+    const unsigned short* W1l = reinterpret_cast<const unsigned short*>(a1.Wblk_lo);
+    const unsigned short* W2h = reinterpret_cast<const unsigned short*>(a2.Wblk);
+    const unsigned short* W2l = reinterpret_cast<const unsigned short*>(a2.Wblk_lo);
+    // copy c (0 .. 8 PL - 1 per wave) of pair p's W1 tiles: tile jj, plane pl, k16 step 4 r + wave
+    const int prow = mlp_row_perm(fr);
+    auto copy_w1 = [&](int p, int c) {
+        const int jj = c / (4 * PL), pl = (c / 4) % PL, sidx = 4 * (c & 3) + wave;
+        const int64_t src = ((int64_t)sidx * N1 + 64 * p + 32 * jj + prow) * 16 + 8 * fc;
+        dma16_unordered((pl ? W1l : W1h) + src, w1buf + (jj * PL + pl) * W1_TILE_B + sidx * 1024);
+    };
+    // copy c (0 .. 8 PL - 1 per wave) of pair p's W2 chunk: plane pl, out tile t = 2 (c & 3) + (wave >> 1), k16 steps 2 (wave & 1) + {0, 1}
+    auto copy_w2 = [&](int p, int c) {
+        const int pl = c / 8, t = (c >> 1) & 3, q = 2 * (wave & 1) + (c & 1), tt = 2 * t + (wave >> 1);
+        const int64_t src = ((int64_t)(4 * p + q) * MLP_D + 32 * tt + fr) * 16 + 8 * fc;
+        dma16_unordered((pl ? W2l : W2h) + src, w2buf + pl * W2_PLANE_B + (tt * 4 + q) * 1024);
+    };
+#pragma unroll
+    for (int c = 0; c < 8 * PL; ++c) copy_w1(0, c);
+
+    // ---- this wave's 32 rows of X -> register fragments (lane: row fr, elements 16 s + 8 fc .. + 7 of every k16 step s)
+    bf16x8 xh[KS], xl[X3 ? KS : 1];
+    {
+        const float* xp = a1.X + row_of(a1.xmap, min(m0 + fr, M - 1)) * a1.ldx + 8 * fc;
+        // all 32 loads of the row are in flight together (the accumulators' registers are still free): one wave per SIMD
+        // means nobody else covers a round trip to memory
+        float4 v[2 * KS];
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) v[i] = *reinterpret_cast<const float4*>(xp + 16 * (i >> 1) + 4 * (i & 1));
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            const float e[8] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w, v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                xh[i][c] = (__bf16)e[c];
+                if constexpr (X3) xl[i][c] = (__bf16)(e[c] - (float)xh[i][c]);
+            }
+        }
+    }
+    f32x16 y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y[t][q] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int n_pairs = N1 / 64;
+    for (int p = 0; p < n_pairs; ++p) {
+        // ---- phase 1: two tiles of H^T; the W2 chunk of this pair is copied meanwhile
+        f32x16 h[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) h[jj][q] = 0.f;
+        {
+            constexpr int AHEAD = 3;
+            bf16x8 wh[AHEAD + 1][2], wl[X3 ? AHEAD + 1 : 1][2];
+            auto read = [&](int sidx) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    wh[sidx % (AHEAD + 1)][jj] = *reinterpret_cast<const bf16x8*>(w1buf + (jj * PL) * W1_TILE_B + (sidx * 64 + lane) * 16);
+                    if constexpr (X3) wl[sidx % (AHEAD + 1)][jj] = *reinterpret_cast<const bf16x8*>(w1buf + (jj * PL + 1) * W1_TILE_B + (sidx * 64 + lane) * 16);
+                }
+            };
+#pragma unroll
+            for (int sidx = 0; sidx < AHEAD; ++sidx) read(sidx);
+            // every copy of the phase goes out at its start: a 64 KB burst per CU takes about a third of the phase to land when
+            // all CUs pull from L2 at once, and a copy issued late would be waited for at the barrier
+            if constexpr (!(ABL & 1)) {
+#pragma unroll
+                for (int c = 0; c < 8 * PL; ++c) copy_w2(p, c);
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < KS; ++sidx) {
+                if (sidx + AHEAD < KS) read(sidx + AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                const int c = sidx % (AHEAD + 1);
+                if constexpr (ABL & 4) { h[0][sidx] += (float)wh[c][0][0] + (float)wh[c][1][1] + (X3 ? (float)wl[c][0][2] + (float)wl[c][1][3] : 0.f); continue; }
+                if constexpr (X3) {
+                    h[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[c][0], xh[sidx], h[0], 0, 0, 0);
+                    h[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[c][1], xh[sidx], h[1], 0, 0, 0);
+                    h[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][0], xl[sidx], h[0], 0, 0, 0);
+                    h[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][1], xl[sidx], h[1], 0, 0, 0);
+                }
+                h[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][0], xh[sidx], h[0], 0, 0, 0);
+                h[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][1], xh[sidx], h[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // bias, activation, split: registers 8 u + 4 e + m of tile jj hold hidden unit 64 p + 32 jj + 16 u + 8 fc + 4 e + m
+        bf16x8 hh[4], hl[X3 ? 4 : 1];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float4 b = *reinterpret_cast<const float4*>(lb1 + 64 * p + 32 * jj + 16 * u + 8 * fc + 4 * e);
+                    const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float v = act_fn(h[jj][8 * u + 4 * e + m] + bv[m], ACT1);
+                        const __bf16 hi = (__bf16)v;
+                        hh[2 * jj + u][4 * e + m] = hi;
+                        if constexpr (X3) hl[2 * jj + u][4 * e + m] = (__bf16)(v - (float)hi);
+                    }
+                }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: Y^T += W2_chunk H^T, four output tiles at a time; the W1 tiles of the next pair are copied meanwhile
+        const bool more = p + 1 < n_pairs;
+        {
+            bf16x8 vh[2][4], vl[X3 ? 2 : 1][4];
+            auto read2 = [&](int g) {             // group g: k16 step g >> 1 of the chunk, output tiles 4 (g & 1) .. + 3
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int off = (((4 * (g & 1) + t) * 4 + (g >> 1)) * 64 + lane) * 16;
+                    vh[g & 1][t] = *reinterpret_cast<const bf16x8*>(w2buf + off);
+                    if constexpr (X3) vl[g & 1][t] = *reinterpret_cast<const bf16x8*>(w2buf + W2_PLANE_B + off);
+                }
+            };
+            read2(0);
+            if (more && !(ABL & 1)) {
+#pragma unroll
+                for (int c = 0; c < 8 * PL; ++c) copy_w1(p + 1, c);
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g + 1 < 8) read2(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int q = g >> 1, t0 = 4 * (g & 1), b = g & 1;
+                if constexpr (ABL & 2) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t0 + t][q] += (float)vh[b][t][q] + (X3 ? (float)vl[b][t][q] : 0.f) + (float)hh[q][t];
+                    continue;
+                }
+                if constexpr (X3) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[b][t], hh[q], y[t0 + t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[b][t], hl[q], y[t0 + t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[b][t], hh[q], y[t0 + t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // ---- epilogue: lane = token fr, register q of tile t = output column 32 t + 8 (q >> 2) + 4 fc + (q & 3).  Four tiles at a
+    // time go through wave-private LDS patches (in the weight buffers, free by now) into "a lane owns four columns of rows
+    // (lane >> 3) + 8 rr"; ALL gate and residual loads of the four tiles are issued before the first store: with one wave per
+    // SIMD every round trip to memory is exposed, and a patch-by-patch epilogue made 32 of them per wave.
+    float* ep = reinterpret_cast<float*>(smem) + wave * (4 * 32 * EP_LD);
+    const int c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& yt = y[4 * half + t];
+                *reinterpret_cast<float4*>(ep + t * (32 * EP_LD) + fr * EP_LD + 8 * g + 4 * fc) = make_float4(yt[4 * g], yt[4 * g + 1], yt[4 * g + 2], yt[4 * g + 3]);
+            }
+        float4 gv[4][4], rv[4][4];
+        int mrow[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = m0 + rr * 8 + (lane >> 3);
+            mrow[rr] = m < M ? m : -1;
+            const int64_t mc = m < M ? m : M - 1;
+            const int64_t grow = a2.gate_group ? (mc / a2.gate_group) * a2.gate_period + mc % a2.gate_period : mc;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = 32 * (4 * half + t) + c4;
+                gv[t][rr] = a2.gate ? *reinterpret_cast<const float4*>(a2.gate + grow * a2.ldg + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+                rv[t][rr] = a2.res ? *reinterpret_cast<const float4*>(a2.res + mc * a2.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = 32 * (4 * half + t) + c4;
+            const float4 bv = *reinterpret_cast<const float4*>(lb2 + n);
+            float v[4][4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4 raw = *reinterpret_cast<const float4*>(ep + t * (32 * EP_LD) + (rr * 8 + (lane >> 3)) * EP_LD + c4);
+                v[rr][0] = raw.x + bv.x; v[rr][1] = raw.y + bv.y; v[rr][2] = raw.z + bv.z; v[rr][3] = raw.w + bv.w;
+            }
+            act_patch<4>(v, a2.act);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (mrow[rr] < 0) continue;
+                const float4 g = gv[t][rr], r = rv[t][rr];
+                *reinterpret_cast<float4*>(a2.Y + (int64_t)mrow[rr] * a2.ldy + n) =
+                    make_float4(fmaf(v[rr][0], g.x, r.x), fmaf(v[rr][1], g.y, r.y), fmaf(v[rr][2], g.z, r.z), fmaf(v[rr][3], g.w, r.w));
+            }
+        }
+    }
+}
+
+template <bool X3>
+static hipError_t launch_mlp256(const LinearArgs& a1, const LinearArgs& a2, hipStream_t stream) {
+    const size_t wbytes = (size_t)(X3 ? 2 : 1) * (2 * 16 * 1024 + 8 * 4 * 1024), epbytes = 4 * 4 * 32 * EP_LD * sizeof(float);
+    const size_t smem = (wbytes > epbytes ? wbytes : epbytes) + (size_t)(a1.N + MLP_D) * sizeof(float);
+    const dim3 grid((unsigned)((a1.M + 127) / 128)), block(256);
+#define ADX_MLP_LAUNCH(ACT)                                                                                                        \
+    {                                                                                                                              \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp256_kernel<X3, ACT>),                 \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+        if (attr != hipSuccess) return attr;                                                                                       \
+        hipLaunchKernelGGL((mlp256_kernel<X3, ACT>), grid, block, smem, stream, a1, a2);                                           \
+        return hipGetLastError();                                                                                                  \
+    }
+    if (X3 && a1.act == ACT_RELU) {                 // measurement hooks (results are wrong): 1 no weight copies after the first, 2 / 4 no products in phase 2 / 1
+        const char* e = getenv("ADX_MLP_ABLATE");
+        const int abl = e ? atoi(e) : 0;
+#define ADX_MLP_ABL(A)                                                                                                             \
+        if (abl == A) {                                                                                                            \
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp256_kernel<X3, ACT_RELU, A>),     \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+            if (attr != hipSuccess) return attr;                                                                                   \
+            hipLaunchKernelGGL((mlp256_kernel<X3, ACT_RELU, A>), grid, block, smem, stream, a1, a2);                               \
+            return hipGetLastError();                                                                                              \
+        }
+        ADX_MLP_ABL(1) ADX_MLP_ABL(2) ADX_MLP_ABL(4) ADX_MLP_ABL(6) ADX_MLP_ABL(7)
+#undef ADX_MLP_ABL
+    }
+    switch (a1.act) {
+        case ACT_RELU: ADX_MLP_LAUNCH(ACT_RELU)
+        case ACT_GELU_TANH: ADX_MLP_LAUNCH(ACT_GELU_TANH)
+        case ACT_NONE: ADX_MLP_LAUNCH(ACT_NONE)
+        default: return hipErrorInvalidValue;
+    }
+#undef ADX_MLP_LAUNCH
+}
+
 // The epilogue of this call can use 16-byte accesses for every operand (the same test the kernels make for themselves).
 static bool linear_vec_ok(const LinearArgs& a) {
     return (a.col_group == 0 || ((a.col_group | a.col_stride | a.col_off) & 3) == 0) && (a.N & 3) == 0 && (a.ldy & 3) == 0 &&
@@ -1338,7 +1619,9 @@ size_t linear_stage_bytes(int M, int N, int K, int prec) { return ((size_t)M + N
 bool linear_planes_ok(int M, int N, int K, int prec) {
     if (prec != PREC_BF16 && prec != PREC_BF16X3) return false;
     const int64_t tiles = (int64_t)((M + G2_TM - 1) / G2_TM) * ((N + G2_TN - 1) / G2_TN);
-    return M >= 256 && N >= 64 && K >= 512 && (K % 64) == 0 && (N & 3) == 0 && tiles >= 320 && (int64_t)M * K < ((int64_t)1 << 31) &&
+    const char* mk = getenv("ADX_PLANES_MIN_K");                  // measurement switch, read per call (default 512)
+    const int min_k = mk ? atoi(mk) : 512;
+    return M >= 256 && N >= 64 && K >= min_k && (K % 64) == 0 && (N & 3) == 0 && tiles >= 320 && (int64_t)M * K < ((int64_t)1 << 31) &&
            (int64_t)N * K < ((int64_t)1 << 31);
 }
 
@@ -1357,6 +1640,21 @@ hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream
     hipLaunchKernelGGL(stage_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned short*>(w), N, K,
                        reinterpret_cast<unsigned short*>(out));
     return hipGetLastError();
+}
+
+// The pair l1 (X -> hidden, bias + activation only) and l2 (hidden -> 256 columns, any epilogue) as one kernel.
+bool mlp256_ok(const LinearArgs& l1, const LinearArgs& l2) {
+    const bool bf = l1.prec == PREC_BF16 || l1.prec == PREC_BF16X3;
+    return bf && l2.prec == l1.prec && l1.M == l2.M && l1.M >= 128 && l1.K == MLP_D && l2.N == MLP_D && l2.K == l1.N && (l1.N % 64) == 0 &&
+           l1.N <= 4096 && l1.X && !l1.Xh && (l1.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(l1.X) & 15) == 0 && l1.in_act == ACT_NONE &&
+           l1.Wblk && l2.Wblk && (l1.prec != PREC_BF16X3 || (l1.Wblk_lo && l2.Wblk_lo)) && !l1.gate && !l1.res && !l1.pos &&
+           l1.col_group == 0 && (l1.act == ACT_RELU || l1.act == ACT_GELU_TANH || l1.act == ACT_NONE) && l2.in_act == ACT_NONE &&
+           l2.col_group == 0 && l2.ymap.per_batch == 0 && linear_vec_ok(l2) && l2.Y && !l2.Yh && !l2.pos;
+}
+
+hipError_t mlp256(const LinearArgs& l1, const LinearArgs& l2, hipStream_t stream) {
+    if (!mlp256_ok(l1, l2)) return hipErrorInvalidValue;
+    return l1.prec == PREC_BF16X3 ? launch_mlp256<true>(l1, l2, stream) : launch_mlp256<false>(l1, l2, stream);
 }
 
 hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {

@@ -91,6 +91,31 @@ def linear_planes(x_planes: torch.Tensor, w_blocked: torch.Tensor, bias: Optiona
     return y
 
 
+def mlp256(x: torch.Tensor, w1_blocked: torch.Tensor, b1: Optional[torch.Tensor], act1: int, w2_blocked: torch.Tensor,
+           b2: Optional[torch.Tensor], act2: int = _lib.ACT_NONE, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+           precision: str = "bf16x3", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``res + gate * act2(act1(x w1^T + b1) w2^T + b2)`` for x (M, 256) in one kernel; weights in ``block_weight`` form."""
+    lib = _lib.load()
+    x = f32c(x)
+    M = x.shape[0]
+    planes = 2 if precision == "bf16x3" else 1
+    nbytes = w1_blocked.numel() * w1_blocked.element_size()
+    N1 = nbytes // (256 * 2 * planes)                   # bf16 elements, one or two planes
+    if N1 * 256 * 2 * planes != nbytes or w2_blocked.numel() * w2_blocked.element_size() != nbytes or x.shape[-1] != 256:
+        raise ValueError("mlp256: x must be (M, 256) and both weights the block_weight form of (N1, 256) / (256, N1) matrices")
+    for t, n in ((b1, N1), (b2, 256), (gate, M * 256), (res, M * 256), (out, M * 256)):
+        if t is not None and t.numel() != n:
+            raise ValueError("mlp256: operand of the wrong size")
+    b1 = f32c(b1) if b1 is not None else None
+    b2 = f32c(b2) if b2 is not None else None
+    gate = f32c(gate) if gate is not None else None
+    res = f32c(res) if res is not None else None
+    y = out if out is not None else torch.empty(M, 256, device=x.device, dtype=torch.float32)
+    check(lib.adx_op_mlp256(ptr(x), ptr(w1_blocked), ptr(b1), int(act1), ptr(w2_blocked), ptr(b2), int(act2), ptr(gate), ptr(res), ptr(y),
+                            M, N1, _lib.PRECISIONS[precision], current_stream()), "adx_op_mlp256")
+    return y
+
+
 def linear_stage_bytes(M: int, N: int, K: int, precision: str) -> int:
     return int(_lib.load().adx_linear_stage_bytes(int(M), int(N), int(K), _lib.PRECISIONS[precision]))
 

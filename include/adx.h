@@ -251,6 +251,14 @@ int adx_engine_profile_read(adx_engine* e, int stage, double* total_ms, int* cou
  * 3 fused tail, 4 per-chunk attention-state build, 5 per-call map-token cache build. */
 int adx_debug_stage_a(adx_engine* e, int B, int stage, int iters, void* stream);
 
+/* Two stacked Linears of a 256-wide model in one kernel, the hidden layer never written to memory:
+ *   y = res + gate * act2(act1(x w1^T + b1) w2^T + b2)        (gate, res nullable: [M][256]; b1, b2 nullable)
+ * x[M][256], w1 = adx_op_block_weight form of a prepared [N1][256] weight, w2 likewise of a [256][N1] weight, N1 a
+ * multiple of 64 (at most 4096), M >= 128, bf16 precisions.  The shape of nn.TransformerEncoderLayer's linear1/linear2 and of
+ * DiTBlock.mlp (libs/diffusionTransformer.py:24-53) at hidden size 256. */
+int adx_op_mlp256(const float* x, const void* w1_blocked, const float* b1, int act1, const void* w2_blocked, const float* b2,
+                  int act2, const float* gate, const float* res, float* y, int M, int N1, int precision, void* stream);
+
 /* DiffusionWrapper.sample_forward / p_sample_loop -- models/diffusion_loss/diffusion_decoder.py:377-446.
  * state[B][S][d_model]; noise[n_noise][B][S][4] (NULL: none with ADX_FLAG_INIT_ZERO, otherwise drawn on the device, see
  * adx_engine_set_noise_seed); out[B][S][4] is de-normalised when ADX_FLAG_NORMALIZE is set. */

@@ -1189,3 +1189,40 @@ def test_device_noise(dev):
     e1 = dd.generate(trajectory_prior=prior, maps_info=maps, seed=9)["traj_logits"].clone()
     init = ops.randn(8, B, fs * 4, seed=9, device=dev).reshape(8, 1, B, fs, 4)
     assert torch.equal(e1, dd.generate(trajectory_prior=prior, maps_info=maps, noise=init)["traj_logits"])
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("act1,act2,extra", [(1, 0, "res"), (3, 3, "gate+res"), (0, 0, "plain")])
+def test_op_mlp256(dev, prec, tol, act1, act2, extra):
+    """The fused two-layer MLP (hidden layer kept on the chip) against the same two products through adx_op_linear and against
+    an fp64 evaluation; M not a multiple of the 128-row workgroup, hidden width 1024 and 192."""
+    from autodiffusion_amd import ops, _lib
+    assert (_lib.ACT_RELU, _lib.ACT_GELU_TANH, _lib.ACT_NONE) == (1, 3, 0)
+    g = torch.Generator().manual_seed(5)
+    for M, N1 in ((1000, 1024), (4096 + 37, 192)):
+        x = torch.randn(M, 256, generator=g)
+        w1, b1 = torch.randn(N1, 256, generator=g) * 0.06, torch.randn(N1, generator=g) * 0.1
+        w2, b2 = torch.randn(256, N1, generator=g) * 0.03, torch.randn(256, generator=g) * 0.1
+        gate = torch.randn(M, 256, generator=g) if "gate" in extra else None
+        res = torch.randn(M, 256, generator=g) if "res" in extra else None
+
+        def act(v, a):
+            return torch.relu(v) if a == 1 else torch.nn.functional.gelu(v, approximate="tanh") if a == 3 else v
+        ref = act(act(x.double() @ w1.double().T + b1.double(), act1) @ w2.double().T + b2.double(), act2)
+        if gate is not None:
+            ref = ref * gate.double()
+        if res is not None:
+            ref = ref + res.double()
+        d = lambda t: None if t is None else t.to(dev)
+        w1p, w2p = ops.prepare_weight(w1.to(dev), prec), ops.prepare_weight(w2.to(dev), prec)
+        y = ops.mlp256(d(x), ops.block_weight(w1p, N1, 256, prec), d(b1), act1, ops.block_weight(w2p, 256, N1, prec), d(b2), act2,
+                       gate=d(gate), res=d(res), precision=prec).cpu()
+        hid = ops.linear(d(x), w1p, d(b1), act=act1, precision=prec, prepared_n=N1)
+        two = ops.linear(hid, w2p, d(b2), act=act2, precision=prec, prepared_n=256).cpu()
+        if gate is not None:
+            two = two * gate
+        if res is not None:
+            two = two + res
+        e, e2 = rel_err(y, ref.float()), rel_err(y, two)
+        print(f"mlp256 {prec} {extra} M={M} N1={N1}: vs fp64 {e:.2e}, vs two products {e2:.2e}")
+        assert e < tol and e2 < tol
