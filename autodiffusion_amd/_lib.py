@@ -23,7 +23,7 @@ FLAG_NORMALIZE, FLAG_RESIDUAL, FLAG_INIT_ZERO, FLAG_NO_GRAPH, FLAG_KEEP_MAPS = 1
 EXPORTS = [
     "adx_abi_version", "adx_last_error",
     "adx_op_timestep_embedding", "adx_op_linear", "adx_op_linear_staged", "adx_linear_stage_bytes", "adx_linear_planes_bytes", "adx_op_stage_planes", "adx_op_block_weight",
-    "adx_op_linear_planes", "adx_op_mlp256", "adx_op_to_bf16", "adx_op_layernorm", "adx_op_attention",
+    "adx_op_linear_planes", "adx_op_mlp256", "adx_op_to_bf16", "adx_op_layernorm", "adx_op_attention", "adx_op_attention_prec",
     "adx_op_normalize", "adx_op_denormalize", "adx_op_sched_step",
     "adx_engine_create", "adx_engine_destroy", "adx_engine_set_tensor", "adx_engine_finalize", "adx_engine_reserve",
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
@@ -74,6 +74,7 @@ def load() -> C.CDLL:
         "adx_op_to_bf16": ([p, p, i64, p], i),
         "adx_op_layernorm": ([p, p, p, p, p, i64, f, i, i64, i, p, p], i),
         "adx_op_mlp256": ([p, p, p, i, p, p, i, p, p, p, i, i, i, p], i),
+        "adx_op_attention_prec": ([p, p, p, p, i, i, i, i, i, i, f, i, i, p], i),
         "adx_op_attention": ([p, p, p, p, i, i, i, i, i, i, f, i, p], i),
         "adx_op_normalize": ([p, p, i64, i, p], i),
         "adx_op_denormalize": ([p, p, p, i64, i, p], i),

@@ -95,6 +95,7 @@ struct AttentionArgs {
     int B = 0, H = 0, Sq = 0, Skv = 0, dh = 0, dv = 0;
     float scale = 1.f;
     int mask_off = -1;
+    int prec = PREC_F32;        // PREC_BF16 / PREC_BF16X3: short unmasked sequences with head dims that are multiples of 32 use the bf16 matrix cores
     // Small-head kernels only.  state != nullptr: instead of O, store the running softmax state of every query,
     // {m, l, o[dh]} per (query, head) with m in log2 units of the scaled score and o un-normalised; row stride
     // state_ld floats (= H * (2 + dh)).  key0 != nullptr: key/value 0 of EVERY batch item are read from

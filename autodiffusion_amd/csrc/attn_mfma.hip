@@ -284,7 +284,238 @@ __global__ __launch_bounds__(512) void attn_mfma_shared_kernel(const AttentionAr
     }
 }
 
+// ============================================================================================================
+// The same attention on the bf16 matrix cores (engine precisions bf16 / split bf16), Sq == Skv <= 128, head dims multiples of
+// 32.  One workgroup per (batch item, head), wave w owns queries 32 w .. 32 w + 31.
+//   scores   S^T[key][q] = K Q^T: A = K tile (lane <-> key), B = Q (lane <-> query).  The accumulator then holds "query on the
+//            lane, keys on the registers": the softmax of a query is a reduction over registers plus one exchange between the
+//            two lane halves, and the probabilities are the B operand of the next product as they stand -- no LDS patch.
+//   output   O^T[c][q] = V^T P^T: A = V^T tile (lane <-> output column, k = keys), B = P^T from the registers; the result has the
+//            query on the lane again, so 1 / sum is applied per lane and a lane stores 16-byte pieces of its query's row.
+// K chunks (all keys x 32 dims) and V chunks (all keys x 32 columns) go through one LDS image as bf16 (high and low halves with
+// split operands), converted once per workgroup; the V image is stored transposed ([column][key], a 4 x 4 register block per
+// thread) with the keys of each group of 16 in the order the accumulator registers imply (index bits 2 and 3 swapped).  The next
+// chunk is fetched into registers while the current one is multiplied.  Rows beyond Skv are zero.
+// ============================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int BK_ROW_B = 80;          // bytes per key row of the K image: 32 bf16 + 16 (conflict-free 16-byte fragment reads)
+
+template <bool X3, int NT>
+__global__ __launch_bounds__(64 * NT) void attn_bf_kernel(const AttentionArgs a, int hpw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char shb[];
+    constexpr int ROWS = 32 * NT, NTHREADS = 64 * NT;
+    constexpr int BV_ROW_B = 64 * NT + 16;                                  // bytes per column row of the V image
+    constexpr int IMG_B = ROWS * BK_ROW_B > 32 * BV_ROW_B ? ROWS * BK_ROW_B : 32 * BV_ROW_B;     // one plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fc = lane >> 5;
+    // A workgroup walks hpw consecutive heads of one item: the first K chunk and queries of the next head are requested while
+    // the last V chunk of the current one is multiplied, so only the first head of a workgroup waits for memory with nothing
+    // else to do (one head per workgroup left these launches bound by the requests in flight).
+    const int h0 = blockIdx.x * hpw, b = blockIdx.y, S = a.Skv;
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + (int64_t)h0 * a.dh;
+    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + (int64_t)h0 * a.dv;
+
+    float4 stage[4];
+    // K chunk: float4 i = tid + NTHREADS j of the ROWS x 8 grid (row i >> 3, 16-byte column i & 7)
+    auto fetch_k = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + NTHREADS * j, row = i >> 3;
+            stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < S) stage[j] = *reinterpret_cast<const float4*>(Kb + (int64_t)row * a.ldk + c + (i & 7) * 4);
+        }
+    };
+    auto split4 = [](const float (&v)[4], bf16x4_t& hi, bf16x4_t& lo) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+    };
+    auto stash_k = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + NTHREADS * j;
+            const float v[4] = {stage[j].x, stage[j].y, stage[j].z, stage[j].w};
+            bf16x4_t hi, lo;
+            split4(v, hi, lo);
+            unsigned char* dst = shb + (i >> 3) * BK_ROW_B + (i & 7) * 8;
+            *reinterpret_cast<bf16x4_t*>(dst) = hi;
+            if constexpr (X3) *reinterpret_cast<bf16x4_t*>(dst + IMG_B) = lo;
+        }
+    };
+    // V chunk: thread = (key group kg = tid >> 3 of four keys, column group cg = tid & 7 of four columns)
+    const int kg = tid >> 3, cg = tid & 7;
+    auto fetch_v = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = 4 * kg + j;
+            stage[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (key < S) stage[j] = *reinterpret_cast<const float4*>(Vb + (int64_t)key * a.ldv + c + 4 * cg);
+        }
+    };
+    auto stash_v = [&]() {
+        const int u = kg & 3, pos = ((4 * kg) & ~15) + 8 * (u & 1) + 4 * (u >> 1);      // keys 4 kg .. + 3 stay together
+        const float col[4][4] = {{stage[0].x, stage[1].x, stage[2].x, stage[3].x}, {stage[0].y, stage[1].y, stage[2].y, stage[3].y},
+                                 {stage[0].z, stage[1].z, stage[2].z, stage[3].z}, {stage[0].w, stage[1].w, stage[2].w, stage[3].w}};
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            bf16x4_t hi, lo;
+            split4(col[ci], hi, lo);
+            unsigned char* dst = shb + (4 * cg + ci) * BV_ROW_B + pos * 2;
+            *reinterpret_cast<bf16x4_t*>(dst) = hi;
+            if constexpr (X3) *reinterpret_cast<bf16x4_t*>(dst + IMG_B) = lo;
+        }
+    };
+    auto split8 = [](const float4& u0, const float4& u1, bf16x8_t& hi, bf16x8_t& lo) {
+        const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+    };
+
+    const int q = 32 * wave + fr;
+    // this lane's k elements of step s: 16 s + 8 fc .. + 7
+    const float* qrow = a.Q + (int64_t)b * a.q_batch_stride + (int64_t)h0 * a.dh + (int64_t)min(q, a.Sq - 1) * a.ldq + 8 * fc;
+    fetch_k(0);
+    float4 qn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qn[j] = *reinterpret_cast<const float4*>(qrow + 16 * (j >> 1) + 4 * (j & 1));
+    for (int hh = 0; hh < hpw; ++hh) {
+    const int h = h0 + hh;
+    // ---- scores
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int c = 0; c < a.dh; c += 32) {
+        __syncthreads();                                            // everyone is done with the previous image
+        stash_k();
+        bf16x8_t qh[2], ql[2];
+        split8(qn[0], qn[1], qh[0], ql[0]);
+        split8(qn[2], qn[3], qh[1], ql[1]);
+        __syncthreads();
+        if (c + 32 < a.dh) {
+            fetch_k(c + 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qn[j] = *reinterpret_cast<const float4*>(qrow + c + 32 + 16 * (j >> 1) + 4 * (j & 1));
+        } else {
+            fetch_v(0);                                             // the first V chunk flies under the last products and the softmax
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const unsigned char* src = shb + (32 * t + fr) * BK_ROW_B + (16 * s + 8 * fc) * 2;
+                const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(src);
+                if constexpr (X3) {
+                    const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(src + IMG_B);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], acc[t], 0, 0, 0);
+            }
+    }
+
+    // ---- softmax of this lane's query: register r of tile t is key 32 t + 8 (r >> 2) + 4 fc + (r & 3)
+    const float f = a.scale * LOG2E_A;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + 8 * (r >> 2) + 4 * fc + (r & 3);
+            acc[t][r] = key < S ? acc[t][r] * f : -INFINITY;
+            mx = fmaxf(mx, acc[t][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    bf16x8_t ph[2 * NT], pl[X3 ? 2 * NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p = exp2_fast(acc[t][8 * u + i] - mx);
+                sum += p;
+                const __bf16 hi = (__bf16)p;
+                ph[2 * t + u][i] = hi;
+                if constexpr (X3) pl[2 * t + u][i] = (__bf16)(p - (float)hi);
+            }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = rcp_fast(sum);
+
+    // ---- output, 32 columns per V chunk
+    for (int c0 = 0; c0 < a.dv; c0 += 32) {
+        __syncthreads();
+        stash_v();
+        __syncthreads();
+        if (c0 + 32 < a.dv) {
+            fetch_v(c0 + 32);
+        } else if (hh + 1 < hpw) {                                  // the next head's first requests
+            Kb += a.dh; Vb += a.dv; qrow += a.dh;
+            fetch_k(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qn[j] = *reinterpret_cast<const float4*>(qrow + 16 * (j >> 1) + 4 * (j & 1));
+        }
+        f32x16_t o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int kq = 0; kq < 2 * NT; ++kq) {
+            const unsigned char* src = shb + fr * BV_ROW_B + (16 * kq + 8 * fc) * 2;
+            const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(src);
+            if constexpr (X3) {
+                const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(src + IMG_B);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[kq], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[kq], o, 0, 0, 0);
+            }
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[kq], o, 0, 0, 0);
+        }
+        if (q < a.Sq) {
+            float* orow = a.O + (int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + (int64_t)h * a.dv + c0 + 4 * fc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(orow + 8 * g) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        }
+    }
+    }
+}
+
+template <bool X3>
+static hipError_t launch_attn_bf(const AttentionArgs& a, hipStream_t stream) {
+    const int nt = (a.Skv + 31) / 32;
+    // heads per workgroup: as many as leave about two thousand workgroups (eight per CU), a divisor of H
+    int hpw = 1;
+    const char* hp_env = getenv("ADX_ATTN_HPW");                // measurement switch, read per call
+    if (hp_env) hpw = atoi(hp_env);
+    else
+        while (hpw * 2 <= a.H && a.H % (hpw * 2) == 0 && (int64_t)a.B * a.H / (hpw * 2) >= 2048) hpw *= 2;
+    if (hpw < 1 || a.H % hpw != 0) hpw = 1;
+    const dim3 grid(a.H / hpw, a.B);
+#define ADX_ATTN_BF(NT)                                                                                                            \
+    {                                                                                                                              \
+        constexpr int img = (32 * NT * BK_ROW_B > 32 * (64 * NT + 16)) ? 32 * NT * BK_ROW_B : 32 * (64 * NT + 16);                 \
+        hipLaunchKernelGGL((attn_bf_kernel<X3, NT>), grid, dim3(64 * NT), (size_t)img * (X3 ? 2 : 1), stream, a, hpw);             \
+        return hipGetLastError();                                                                                                  \
+    }
+    switch (nt) {
+        case 1: ADX_ATTN_BF(1)
+        case 2: ADX_ATTN_BF(2)
+        case 3: ADX_ATTN_BF(3)
+        case 4: ADX_ATTN_BF(4)
+        default: return hipErrorInvalidValue;
+    }
+#undef ADX_ATTN_BF
+}
+
 }  // namespace
+
+static bool attention_bf_ok(const AttentionArgs& a) {
+    return (a.prec == PREC_BF16 || a.prec == PREC_BF16X3) && a.Sq == a.Skv && a.Skv <= 128 && (a.dh % 32) == 0 && (a.dv % 32) == 0 &&
+           (a.ldv % 4) == 0 && (a.v_batch_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a.V) & 15) == 0 &&
+           (a.ldo % 4) == 0 && (a.o_batch_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a.O) & 15) == 0 && a.H <= 65535 && a.B <= 65535;
+}
 
 static bool attention_shared_ok(const AttentionArgs& a) {
     return a.Sq == a.Skv && (a.dh % 32) == 0 && (a.dv % 32) == 0 && (a.ldv % 4) == 0 && (a.v_batch_stride % 4) == 0 &&
@@ -299,6 +530,9 @@ bool attention_mfma_ok(const AttentionArgs& a) {
 
 hipError_t attention_mfma(const AttentionArgs& a, hipStream_t stream) {
     if (!attention_mfma_ok(a)) return hipErrorInvalidValue;
+    const char* f32_env = getenv("ADX_ATTN_F32");                // measurement switch, read per call: 1 = the fp32 kernels in every precision
+    if (attention_bf_ok(a) && !(f32_env && f32_env[0] == '1'))
+        return a.prec == PREC_BF16X3 ? launch_attn_bf<true>(a, stream) : launch_attn_bf<false>(a, stream);
     static const bool no_shared = [] { const char* e = getenv("ADX_ATTN_NO_SHARED"); return e && e[0] == '1'; }();   // measurement switch
     if (!no_shared && attention_shared_ok(a)) {
         const int n_kt = (a.Skv + 15) / 16, p_ld = 16 * n_kt + 4;

@@ -445,10 +445,25 @@ ADX_API int adx_op_layernorm(const float* x, const float* gamma, const float* be
     return done(layernorm(a, (hipStream_t)stream), "layernorm");
 }
 
+static int op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh, int dv, float scale,
+                        int mask_off, int prec, void* stream);
+
 ADX_API int adx_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh,
                              int dv, float scale, int mask_off, void* stream) {
+    return op_attention(q, k, v, o, B, H, Sq, Skv, dh, dv, scale, mask_off, ADX_PREC_F32, stream);
+}
+
+ADX_API int adx_op_attention_prec(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh,
+                                  int dv, float scale, int mask_off, int precision, void* stream) {
+    if (precision != ADX_PREC_F32 && precision != ADX_PREC_BF16 && precision != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "attention: unknown precision");
+    return op_attention(q, k, v, o, B, H, Sq, Skv, dh, dv, scale, mask_off, precision, stream);
+}
+
+static int op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh, int dv, float scale,
+                        int mask_off, int prec, void* stream) {
     if (!q || !k || !v || !o) return fail(ADX_EINVAL, "attention: null pointer");
     AttentionArgs a;
+    a.prec = prec;
     a.Q = q; a.ldq = (int64_t)H * dh; a.q_batch_stride = (int64_t)Sq * H * dh;
     a.K = k; a.ldk = (int64_t)H * dh; a.k_batch_stride = (int64_t)Skv * H * dh;
     a.V = v; a.ldv = (int64_t)H * dv; a.v_batch_stride = (int64_t)Skv * H * dv;

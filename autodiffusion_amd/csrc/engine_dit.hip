@@ -274,6 +274,7 @@ struct EngineDiT final : adx_engine {
                 at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)S * 3 * d;
                 at.O = ATT; at.ldo = d; at.o_batch_stride = (int64_t)S * d;
                 at.B = B; at.H = H; at.Sq = S; at.Skv = S; at.dh = dh; at.dv = dh; at.scale = 1.0f / sqrtf((float)dh); at.mask_off = -1;
+                at.prec = prec;
                 ADX_HIP(attention(at, s));
                 LinearArgs o = lin(ATT, d, p + ".attn.self_attn.out_proj.weight", 0, d, d, p + ".attn.self_attn.out_proj.bias", Z0, d, R);
                 o.res = HN; o.ldr = d;
@@ -336,6 +337,7 @@ struct EngineDiT final : adx_engine {
                 at.q_batch_stride = at.k_batch_stride = at.v_batch_stride = (int64_t)S * hd * H;
                 at.O = ATT; at.ldo = (int64_t)hd * H; at.o_batch_stride = (int64_t)S * hd * H;
                 at.B = B; at.H = H; at.Sq = S; at.Skv = S; at.dh = hd; at.dv = hd; at.scale = 1.0f / sqrtf((float)kd); at.mask_off = -1;
+                at.prec = cfg.precision;
                 ADX_HIP(attention(at, s));
                 ADX_HIP(linear(lin(ATT, (int64_t)hd * H, p + ".attn.proj.weight", 0, d, hd * H, p + ".attn.proj.bias", OB, d, R), s));
                 for (int st = 0; st < 2; ++st) {

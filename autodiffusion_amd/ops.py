@@ -136,7 +136,7 @@ def layernorm(x: torch.Tensor, gamma=None, beta=None, shift=None, scale=None, ep
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_head: int, scale: Optional[float] = None,
-              mask_off: int = -1) -> torch.Tensor:
+              mask_off: int = -1, precision: str = "fp32") -> torch.Tensor:
     """q (B,Sq,H*dh), k (B,Skv,H*dh), v (B,Skv,H*dv) -> (B,Sq,H*dv)."""
     lib = _lib.load()
     q, k, v = f32c(q), f32c(k), f32c(v)
@@ -145,8 +145,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_head: int, sc
     if scale is None:
         scale = dh ** -0.5
     o = torch.empty(B, Sq, n_head * dv, device=q.device, dtype=torch.float32)
-    check(lib.adx_op_attention(ptr(q), ptr(k), ptr(v), ptr(o), B, n_head, Sq, Skv, dh, dv, float(scale), mask_off, current_stream()),
-          "attention")
+    check(lib.adx_op_attention_prec(ptr(q), ptr(k), ptr(v), ptr(o), B, n_head, Sq, Skv, dh, dv, float(scale), mask_off,
+                                    _lib.PRECISIONS[precision], current_stream()), "attention")
     return o
 
 

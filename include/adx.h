@@ -118,6 +118,11 @@ int adx_op_layernorm(const float* x, const float* gamma, const float* beta, cons
  * torch.nn.MultiheadAttention core / DiT_Attention.forward (libs/diffusionTransformer.py:99-117). */
 int adx_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh,
                      int dv, float scale, int mask_off, void* stream);
+/* The same with the engine's operand precision: under ADX_PREC_BF16 / ADX_PREC_BF16X3 unmasked attention with Sq == Skv <= 128
+ * and head widths that are multiples of 32 (every DiT / MM-DiT block) runs on the bf16 matrix cores, scores and probabilities
+ * rounded to bf16 (split into high + low halves under BF16X3); other shapes and ADX_PREC_F32 are adx_op_attention. */
+int adx_op_attention_prec(const float* q, const float* k, const float* v, float* o, int B, int H, int Sq, int Skv, int dh,
+                          int dv, float scale, int mask_off, int precision, void* stream);
 
 /* normalize / denormalize -- models/utils.py:56-80 (C = 4 or 2 channels). `residual` may be NULL. */
 int adx_op_normalize(const float* x, float* y, int64_t n_points, int C, void* stream);

@@ -1226,3 +1226,22 @@ def test_op_mlp256(dev, prec, tol, act1, act2, extra):
         e, e2 = rel_err(y, ref.float()), rel_err(y, two)
         print(f"mlp256 {prec} {extra} M={M} N1={N1}: vs fp64 {e:.2e}, vs two products {e2:.2e}")
         assert e < tol and e2 < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("S,H,dh", [(80, 8, 32), (80, 2, 512), (33, 3, 64), (128, 2, 32), (17, 1, 96)])
+def test_op_attention_bf16_matrix_cores(dev, prec, tol, S, H, dh):
+    """Unmasked attention with Sq == Skv <= 128 on the bf16 matrix cores (one to four key tiles, ragged last tile, 1 to 16 chunks
+    of the head width) against an fp64 softmax attention and against the fp32 kernel."""
+    from autodiffusion_amd import ops
+    g = torch.Generator().manual_seed(S * 1000 + dh)
+    B = 3
+    q, k, v = (torch.randn(B, S, H * dh, generator=g) for _ in range(3))
+    q = q * 1.5
+    ref = torch.nn.functional.scaled_dot_product_attention(*(t.double().reshape(B, S, H, dh).transpose(1, 2) for t in (q, k, v)))
+    ref = ref.transpose(1, 2).reshape(B, S, H * dh).float()
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), H, precision=prec).cpu()
+    f32 = ops.attention(q.to(dev), k.to(dev), v.to(dev), H).cpu()
+    e, e32 = rel_err(out, ref), rel_err(f32, ref)
+    print(f"attention {prec} S={S} H={H} dh={dh}: vs fp64 {e:.2e} (fp32 kernel {e32:.2e})")
+    assert e < tol and e32 < 1e-5
