@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, con
         // means nobody else covers a round trip to memory
         float4 v[2 * KS];
 #pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) v[i] = *reinterpret_cast<const float4*>(xp + 16 * (i >> 1) + 4 * (i & 1));
+        for (int i = 0; i < 2 * KS; ++i) v[i] = (ABL & 16) ? make_float4(0.5f, 0.25f, 1.f, 2.f) : *reinterpret_cast<const float4*>(xp + 16 * (i >> 1) + 4 * (i & 1));
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
             const float e[8] = {v[2 * i].x, v[2 * i].y, v[2 * i].z, v[2 * i].w, v[2 * i + 1].x, v[2 * i + 1].y, v[2 * i + 1].z, v[2 * i + 1].w};
@@ -1386,24 +1386,29 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, con
     __builtin_amdgcn_s_barrier();
     const int n_pairs = N1 / 64;
     for (int p = 0; p < n_pairs; ++p) {
-        // ---- phase 1: two tiles of H^T; the W2 chunk of this pair is copied meanwhile
+        // ---- phase 1: two tiles of H^T, one after the other; the W2 chunk of this pair is copied meanwhile.  Bias, activation
+        // and split of tile 0 run in slices between the products of tile 1 (and those of tile 1 between the first products of
+        // phase 2, which only read tile 0's half of H): with one wave per SIMD a separate activation section would idle the
+        // matrix pipe.  Register 8 u + 4 e + m of tile jj holds hidden unit 64 p + 32 jj + 16 u + 8 fc + 4 e + m.
         f32x16 h[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) h[jj][q] = 0.f;
+        bf16x8 hh[4], hl[X3 ? 4 : 1];
+        auto act_slice = [&](int jj, int r) {
+            const int u = r >> 3, i = r & 7;
+            const float v = act_fn(h[jj][r] + lb1[64 * p + 32 * jj + 16 * u + 8 * fc + i], ACT1);
+            const __bf16 hi = (__bf16)v;
+            hh[2 * jj + u][i] = hi;
+            if constexpr (X3) hl[2 * jj + u][i] = (__bf16)(v - (float)hi);
+        };
         {
             constexpr int AHEAD = 3;
-            bf16x8 wh[AHEAD + 1][2], wl[X3 ? AHEAD + 1 : 1][2];
-            auto read = [&](int sidx) {
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    wh[sidx % (AHEAD + 1)][jj] = *reinterpret_cast<const bf16x8*>(w1buf + (jj * PL) * W1_TILE_B + (sidx * 64 + lane) * 16);
-                    if constexpr (X3) wl[sidx % (AHEAD + 1)][jj] = *reinterpret_cast<const bf16x8*>(w1buf + (jj * PL + 1) * W1_TILE_B + (sidx * 64 + lane) * 16);
-                }
+            bf16x8 wh[AHEAD + 1], wl[X3 ? AHEAD + 1 : 1];
+            auto read = [&](int k) {            // k = 16 jj + step
+                const int jj = k >> 4, sidx = k & 15;
+                wh[k % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(w1buf + (jj * PL) * W1_TILE_B + (sidx * 64 + lane) * 16);
+                if constexpr (X3) wl[k % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(w1buf + (jj * PL + 1) * W1_TILE_B + (sidx * 64 + lane) * 16);
             };
 #pragma unroll
-            for (int sidx = 0; sidx < AHEAD; ++sidx) read(sidx);
+            for (int k = 0; k < AHEAD; ++k) read(k);
             // every copy of the phase goes out at its start: a 64 KB burst per CU takes about a third of the phase to land when
             // all CUs pull from L2 at once, and a copy issued late would be waited for at the barrier
             if constexpr (!(ABL & 1)) {
@@ -1411,40 +1416,28 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, con
                 for (int c = 0; c < 8 * PL; ++c) copy_w2(p, c);
             }
 #pragma unroll
-            for (int sidx = 0; sidx < KS; ++sidx) {
-                if (sidx + AHEAD < KS) read(sidx + AHEAD);
+            for (int k = 0; k < 2 * KS; ++k) {
+                const int jj = k >> 4, sidx = k & 15;
+                if (k + AHEAD < 2 * KS) read(k + AHEAD);
                 __builtin_amdgcn_sched_barrier(0);
-                const int c = sidx % (AHEAD + 1);
-                if constexpr (ABL & 4) { h[0][sidx] += (float)wh[c][0][0] + (float)wh[c][1][1] + (X3 ? (float)wl[c][0][2] + (float)wl[c][1][3] : 0.f); continue; }
-                if constexpr (X3) {
-                    h[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[c][0], xh[sidx], h[0], 0, 0, 0);
-                    h[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[c][1], xh[sidx], h[1], 0, 0, 0);
-                    h[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][0], xl[sidx], h[0], 0, 0, 0);
-                    h[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][1], xl[sidx], h[1], 0, 0, 0);
+                const int c = k % (AHEAD + 1);
+                if (sidx == 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) h[jj][q] = 0.f;
                 }
-                h[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][0], xh[sidx], h[0], 0, 0, 0);
-                h[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c][1], xh[sidx], h[1], 0, 0, 0);
+                if constexpr (ABL & 4) {
+                    h[jj][sidx] += (float)wh[c][0] + (X3 ? (float)wl[c][2] : 0.f);
+                } else {
+                    if constexpr (X3) {
+                        h[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[c], xh[sidx], h[jj], 0, 0, 0);
+                        h[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c], xl[sidx], h[jj], 0, 0, 0);
+                    }
+                    h[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[c], xh[sidx], h[jj], 0, 0, 0);
+                }
+                if (jj == 1) act_slice(0, sidx);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // bias, activation, split: registers 8 u + 4 e + m of tile jj hold hidden unit 64 p + 32 jj + 16 u + 8 fc + 4 e + m
-        bf16x8 hh[4], hl[X3 ? 4 : 1];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float4 b = *reinterpret_cast<const float4*>(lb1 + 64 * p + 32 * jj + 16 * u + 8 * fc + 4 * e);
-                    const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const float v = act_fn(h[jj][8 * u + 4 * e + m] + bv[m], ACT1);
-                        const __bf16 hi = (__bf16)v;
-                        hh[2 * jj + u][4 * e + m] = hi;
-                        if constexpr (X3) hl[2 * jj + u][4 * e + m] = (__bf16)(v - (float)hi);
-                    }
-                }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // ---- phase 2: Y^T += W2_chunk H^T, four output tiles at a time; the W1 tiles of the next pair are copied meanwhile
@@ -1472,16 +1465,20 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, con
                 if constexpr (ABL & 2) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) y[t0 + t][q] += (float)vh[b][t][q] + (X3 ? (float)vl[b][t][q] : 0.f) + (float)hh[q][t];
-                    continue;
+                } else {
+                    if constexpr (X3) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[b][t], hh[q], y[t0 + t], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[b][t], hl[q], y[t0 + t], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[b][t], hh[q], y[t0 + t], 0, 0, 0);
                 }
-                if constexpr (X3) {
+                if (g < 4) {                      // tile 1's half of H is first read by group 4
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[b][t], hh[q], y[t0 + t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[b][t], hl[q], y[t0 + t], 0, 0, 0);
+                    for (int r = 4 * g; r < 4 * g + 4; ++r) act_slice(1, r);
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) y[t0 + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[b][t], hh[q], y[t0 + t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1514,8 +1511,8 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, con
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int n = 32 * (4 * half + t) + c4;
-                gv[t][rr] = a2.gate ? *reinterpret_cast<const float4*>(a2.gate + grow * a2.ldg + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-                rv[t][rr] = a2.res ? *reinterpret_cast<const float4*>(a2.res + mc * a2.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                gv[t][rr] = (a2.gate && !(ABL & 8)) ? *reinterpret_cast<const float4*>(a2.gate + grow * a2.ldg + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+                rv[t][rr] = (a2.res && !(ABL & 8)) ? *reinterpret_cast<const float4*>(a2.res + mc * a2.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
@@ -1532,6 +1529,7 @@ __global__ __launch_bounds__(256, 1) void mlp256_kernel(const LinearArgs a1, con
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 if (mrow[rr] < 0) continue;
+                if ((ABL & 8) && v[rr][0] != 12345.f) continue;
                 const float4 g = gv[t][rr], r = rv[t][rr];
                 *reinterpret_cast<float4*>(a2.Y + (int64_t)mrow[rr] * a2.ldy + n) =
                     make_float4(fmaf(v[rr][0], g.x, r.x), fmaf(v[rr][1], g.y, r.y), fmaf(v[rr][2], g.z, r.z), fmaf(v[rr][3], g.w, r.w));
@@ -1553,7 +1551,7 @@ static hipError_t launch_mlp256(const LinearArgs& a1, const LinearArgs& a2, hipS
         hipLaunchKernelGGL((mlp256_kernel<X3, ACT>), grid, block, smem, stream, a1, a2);                                           \
         return hipGetLastError();                                                                                                  \
     }
-    if (X3 && a1.act == ACT_RELU) {                 // measurement hooks (results are wrong): 1 no weight copies after the first, 2 / 4 no products in phase 2 / 1
+    if (X3 && a1.act == ACT_RELU) {                 // measurement hooks (results are wrong): 1 no weight copies after the first, 2 / 4 no products in phase 2 / 1, 8 no epilogue loads and stores, 16 no X loads
         const char* e = getenv("ADX_MLP_ABLATE");
         const int abl = e ? atoi(e) : 0;
 #define ADX_MLP_ABL(A)                                                                                                             \
@@ -1564,7 +1562,7 @@ static hipError_t launch_mlp256(const LinearArgs& a1, const LinearArgs& a2, hipS
             hipLaunchKernelGGL((mlp256_kernel<X3, ACT_RELU, A>), grid, block, smem, stream, a1, a2);                               \
             return hipGetLastError();                                                                                              \
         }
-        ADX_MLP_ABL(1) ADX_MLP_ABL(2) ADX_MLP_ABL(4) ADX_MLP_ABL(6) ADX_MLP_ABL(7)
+        ADX_MLP_ABL(1) ADX_MLP_ABL(2) ADX_MLP_ABL(4) ADX_MLP_ABL(6) ADX_MLP_ABL(7) ADX_MLP_ABL(15) ADX_MLP_ABL(23) ADX_MLP_ABL(31) ADX_MLP_ABL(24)
 #undef ADX_MLP_ABL
     }
     switch (a1.act) {

@@ -17,7 +17,8 @@ w2b = ops.block_weight(ops.prepare_weight(torch.randn(256, N1, device=dev) * 0.0
 b1, b2 = torch.randn(N1, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
 res, y = torch.randn(M, 256, device=dev), torch.empty(M, 256, device=dev)
 names = {0: "everything", 1: "no weight copies after the first", 2: "no products in phase 2", 4: "no products in phase 1", 6: "no products at all",
-         7: "no products, no copies"}
+         7: "no products, no copies", 15: "no products, no copies, no epilogue memory traffic", 23: "no products, no copies, no X loads",
+         31: "no products, no copies, no global memory traffic at all", 24: "everything but the X loads and the epilogue traffic"}
 run = lambda: ops.mlp256(x, w1b, b1, _lib.ACT_RELU, w2b, b2, res=res, precision=prec, out=y)
 for _ in range(40):
     run()
