@@ -329,3 +329,20 @@ def test_metrics_host_formulas(golden):
         assert a.keys() == b.keys()
         for k in a:
             assert abs(a[k] - b[k]) < 1e-5 * max(1.0, abs(b[k])), (S, C, k, a[k], b[k])
+
+
+def test_mlp256_rejects_mismatched_operands():
+    """The Python wrapper of the fused MLP derives the hidden width from the weight buffers' BYTE size and refuses operands that do
+    not fit it (a wrong width would send the kernel's weight copies out of bounds)."""
+    from autodiffusion_amd import ops
+    x = torch.zeros(128, 256)
+    w1 = torch.zeros(64 * 256 * 2 * 2, dtype=torch.uint8)           # block_weight form of a (64, 256) weight, two planes
+    w2 = torch.zeros(64 * 256 * 2 * 2, dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        ops.mlp256(x, w1, torch.zeros(65), 1, w2, None)              # bias of the wrong length
+    with pytest.raises(ValueError):
+        ops.mlp256(x, w1, None, 1, w2[:-2], None)                    # second weight of another size
+    with pytest.raises(ValueError):
+        ops.mlp256(torch.zeros(128, 128), w1, None, 1, w2, None)     # not 256 wide
+    with pytest.raises(ValueError):
+        ops.mlp256(x, w1, None, 1, w2, None, res=torch.zeros(127, 256))
