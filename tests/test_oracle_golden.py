@@ -128,8 +128,11 @@ def test_normalize_posemb_metrics(golden):
     t = T(g["posemb_t"])
     for d in (32, 256, 1024):
         e = nets.sinusoidal_pos_emb(t, d).numpy()
-        np.testing.assert_allclose(e, g[f"posemb_a_{d}"], atol=2e-6)
-        np.testing.assert_allclose(e, g[f"posemb_b_{d}"], atol=2e-6)
+        # exp() of the frequency table may differ by one ulp between CPUs (vector-math builds); the
+        # sine's argument t*f then moves by up to |t| * 2^-23, so the gate grows with |t|
+        tol = 2e-6 + 1.2e-7 * np.abs(t.numpy()).reshape(-1, 1)
+        assert (np.abs(e - g[f"posemb_a_{d}"]) <= tol).all()
+        assert (np.abs(e - g[f"posemb_b_{d}"]) <= tol).all()
     m = golden("g10_metrics")
     got = sampling.displacement_metrics(m["pred"], m["label"])
     for k, v in got.items():
