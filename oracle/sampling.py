@@ -166,6 +166,22 @@ def refiner_loss(denoise_cond: Callable, b: Dict[str, np.ndarray], objective: st
     return (loss * torch.as_tensor(b["loss_weight"], dtype=torch.float32)[t]).mean()
 
 
+def refiner_loss_grads(sd: Dict[str, torch.Tensor], forward: Callable, b: Dict[str, np.ndarray], objective: str, maps_info, transition_info,
+                       trajectory_prior, x_start, t: torch.Tensor, noise: torch.Tensor, auto_normalize: bool = True):
+    """What ``loss.backward()`` leaves in the denoiser's parameters after TrajectoryRefiner.forward (TrajRefiner.py:100-121 ->
+    p_losses :417-452): reverse-mode differentiation of :func:`refiner_loss` over the restated network
+    ``forward(sd, x, t, maps, transition_n, prior_n)``.  Returns (loss, {parameter name: gradient}); parameters that do not
+    reach the loss (the mask buffers) are left out."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point()}
+    full = dict(sd)
+    full.update(leaves)
+    loss = refiner_loss(lambda x, tt, tra_n, pri_n: forward(full, x, tt, maps_info, tra_n, pri_n), b, objective, transition_info,
+                        trajectory_prior, x_start, t, noise, auto_normalize)
+    names = list(leaves)
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
+    return loss.detach(), {k: g for k, g in zip(names, grads) if g is not None}
+
+
 def refiner_forward(denoise_cond: Callable, b, objective: str, prior_full, label_full, init_x, t, noise, frame_stack: int,
                     residual: bool = False, auto_normalize: bool = True, rescale: float = 1.0):
     """DiffusionAugmentation.forward (DiffusionAugmentation.py:75-135), loss part: chunk c is scored with the prior chunk,

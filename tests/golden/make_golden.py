@@ -505,8 +505,40 @@ def g13_forward_loss():
     save("g13_forward_loss", **out)
 
 
+# ----------------------------------------------------------------------------- G14: parameter gradients of the training loss
+def g14_refiner_grads():
+    """loss.backward() of the reference's TrajectoryRefiner.forward (TrajRefiner.py:100-121 -> p_losses :417-452) for one chunk of
+    the frame_stack-10 / 100-step / pred_noise configuration: timesteps and noise supplied, dropout off (the denoiser is in eval
+    mode), seeded weights with non-zero biases.  Stored: the loss and the gradient of every denoiser parameter."""
+    out = {}
+    B, fs, N = 2, 10, 100
+    maps = synth.maps_info(B, ISEED)
+    prior = synth.trajectory_prior(B, ISEED)
+    label = prior + synth.noise(B, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    refiner = _refiner(fs, N, "pred_noise", "cosine", False, init="seeded")
+    refiner.train()
+    refiner.diffusion.model.eval()
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    t = torch.tensor([37, 81], dtype=torch.long)
+    nz = synth.noise(B, (), (fs, 4), NSEED + 3)
+    with noise_queue([nz]) as q, fixed_randint([t]) as qt:
+        loss, _ = refiner(label[:, :fs].clone(), init_x[None].expand(B, fs, 4).clone(), prior[:, :fs].clone(), maps)
+        assert not q and not qt
+    loss.backward()
+    out["t"] = t
+    out["loss"] = loss.detach()
+    n = 0
+    for name, p in refiner.diffusion.model.named_parameters():
+        if p.grad is None:
+            continue
+        out["grad." + name] = p.grad
+        n += p.grad.numel()
+    print("g14:", n, "gradient values, loss", float(loss))
+    save("g14_refiner_grads", **out)
+
+
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
-       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss}
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

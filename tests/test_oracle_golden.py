@@ -409,6 +409,35 @@ def test_forward_loss(golden, tag, fs, N, obj, sched, residual):
     np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=2e-4)
 
 
+def g14_case():
+    """Inputs of the gradient fixture: chunk 0 of the frame_stack-10 / 100-step / pred_noise configuration, batch 2."""
+    fs = 10
+    maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
+    label = prior + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    return dict(maps=maps, prior=prior[:, :fs].contiguous(), label=label[:, :fs].contiguous(),
+                transition=init_x[None].expand(2, fs, 4).contiguous(), noise=synth.noise(2, (), (fs, 4), NSEED + 3))
+
+
+def grad_rel_err(got, want):
+    want = torch.as_tensor(want)
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+def test_refiner_loss_gradients(golden):
+    """Reverse-mode gradients of the restated loss against what the reference's own backward() left in its parameters."""
+    g = golden("g14_refiner_grads")
+    c = g14_case()
+    sd = reference_init_refiner_sd(10, 100, init="seeded")
+    loss, grads = sampling.refiner_loss_grads(sd, nets.variant_a_forward, schedules.buffers("cosine", 100, "pred_noise"), "pred_noise",
+                                              c["maps"], c["transition"], c["prior"], c["label"], T(g["t"]), c["noise"])
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=2e-5)
+    want = {k[len("grad."):]: v for k, v in g.items() if k.startswith("grad.")}
+    assert set(want) == set(grads) and len(want) == 108
+    for k, v in want.items():
+        assert grad_rel_err(grads[k], v) < 2e-4, k
+
+
 @pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
 def test_twin_forward_loss(golden, backbone):
     g = golden("g13_forward_loss")
