@@ -1,0 +1,435 @@
+// Backward kernels of the refiner's training path (the reference trains its denoiser under torch autograd:
+// TrajRefiner.py:417-452 builds the loss, loss.backward() differentiates transformer.py:189-273).  Everything here is fp32:
+//   * weight / bias gradients of a Linear, dW = dY^T X and db = column sums of dY, on the fp32 matrix cores
+//     (v_mfma_f32_32x32x2_f32: exact f32 products, one accumulation chain per output element), partial sums per row chunk
+//     combined in a fixed order, so the result does not depend on the launch timing (no atomics);
+//   * LayerNorm backward (input gradient + the per-element products whose column sums are the gain gradient);
+//   * softmax attention backward for small head widths (the refiner's heads are 4 wide: vector arithmetic, not matrix
+//     cores), recomputing the probabilities from q, k and the saved log-sum-exp instead of storing an Sq x Skv matrix;
+//   * exact-erf GELU forward / backward, the gradient of the weighted squared error, transpose, add, column sums.
+// The input gradient of a Linear, dX = dY W, is adx_op_linear on the transposed weight.
+#include "engine.h"
+
+#include <math.h>
+
+using namespace adx;
+
+#define ADX_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+int fail(int code, const char* msg) { set_error(msg); return code; }
+int done(hipError_t e, const char* what) { return e == hipSuccess ? ADX_OK : hip_fail(e, what); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// y = x Phi(x), Phi the standard normal distribution function (torch's default "gelu": the erf form)
+__global__ __launch_bounds__(256) void gelu_kernel(const float* x, float* y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = 0.5f * v * erfcf(-v * 0.70710678118654752f); }
+}
+
+// dx = dy (Phi(x) + x phi(x)), phi the standard normal density
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* x, const float* dy, float* dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float cdf = 0.5f * erfcf(-v * 0.70710678118654752f);
+    const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+    dx[i] = dy[i] * fmaf(v, pdf, cdf);
+}
+
+// d loss / d out for loss = mean_b( w[t_b] * mean_e (out - target)^2 ), times the upstream scalar gradient
+__global__ __launch_bounds__(256) void weighted_mse_bwd_kernel(const float* out, const float* target, const int64_t* t, const float* weight,
+                                                                const float* upstream, float* dout, int64_t total, int row_len, float inv_count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float g = (upstream ? upstream[0] : 1.0f) * 2.0f * inv_count * weight[t[i / row_len]];
+    dout[i] = g * (out[i] - target[i]);
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = x[(int64_t)(r0 + j) * cols + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) y[(int64_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// partial[chunk][c] = sum of x[r][c] over the rows of the chunk.  A workgroup covers a tile of up to 256 columns; when the
+// tile is narrower, 256 / width row phases share it and are combined through LDS in phase order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, int64_t M, int N, int64_t rows_per_chunk, float* partial) {
+    __shared__ float red[256];
+    const int c0 = blockIdx.x * 256;
+    const int width = min(256, N - c0);
+    const int P = 256 / width;
+    const int c = threadIdx.x % width, p = threadIdx.x / width;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (p < P)
+        for (int64_t r = r0 + p; r < r1; r += P) s += x[r * N + c0 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (p == 0) {
+        for (int q = 1; q < P; ++q) s += red[q * width + c];
+        partial[(int64_t)blockIdx.y * N + c0 + c] = s;
+    }
+}
+
+// out[i] (+)= sum over chunks of partial[chunk * stride + i], chunks in ascending order
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int n_chunks, int64_t stride, int64_t n, float* out, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int ch = 0; ch < n_chunks; ++ch) s += partial[(int64_t)ch * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------ dW = dY^T X, db = colsum(dY)
+// One workgroup per (32 x 32 tile of dW, row chunk).  v_mfma_f32_32x32x2_f32 contracts two rows per instruction: lane l
+// supplies dY[row + l / 32][n0 + l % 32] as the A operand and X[row + l / 32][k0 + l % 32] as the B operand -- both are plain
+// coalesced loads, nothing is staged.  Each of the four waves walks a quarter of the chunk with four independent
+// accumulation chains; the waves' tiles are added through LDS in wave order.
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* dy, const float* x, int64_t M, int N, int K, int64_t rows_per_chunk,
+                                                             float* partial, int64_t partial_stride, int want_bias) {
+    __shared__ float red[4][17][64];
+    const int kt_n = (K + 31) >> 5;
+    const int nt = blockIdx.x / kt_n, kt = blockIdx.x % kt_n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int n = nt * 32 + col, k = kt * 32 + col;
+    const bool n_ok = n < N, k_ok = k < K;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const int64_t quarter = rows_per_chunk >> 2;                    // rows_per_chunk is a multiple of 32
+    const int64_t w0 = r0 + wave * quarter, w1 = min(r1, w0 + quarter);
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bsum = 0.f;
+    for (int64_t base = w0; base < w1; base += 8) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t rr = base + 2 * j + half;
+            const bool ok = rr < w1;
+            a[j] = (ok && n_ok) ? dy[rr * N + n] : 0.f;
+            b[j] = (ok && k_ok) ? x[rr * K + k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0);
+            bsum += a[j];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+    red[wave][16][lane] = bsum;
+    __syncthreads();
+    if (wave != 0) return;
+    float* out = partial + (int64_t)blockIdx.y * partial_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+        const int m = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);           // accumulator register r of this lane: row m, column col
+        if (m < N && k_ok) out[(int64_t)m * K + k] = s;
+    }
+    if (want_bias && kt == 0 && half == 0 && n_ok) {
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += red[w][16][lane] + red[w][16][lane + 32];
+        out[(int64_t)N * K + n] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// G lanes per row.  y = xhat * gamma + beta with xhat = (x - mean) * rstd:
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;   dgamma = colsum(dy * xhat),  dbeta = colsum(dy).
+template <int G>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* gamma, const float* dy, int64_t rows, int d, float eps,
+                                                             float* dx, float* dy_xhat) {
+    const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int sub = threadIdx.x % G;
+    if (row >= rows) return;                                        // uniform over the G lanes of a row
+    const float* xr = x + row * d;
+    const float* gr = dy + row * d;
+    float s = 0.f;
+    for (int e = sub; e < d; e += G) s += xr[e];
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, G);
+    const float mean = s / (float)d;
+    float q = 0.f;
+    for (int e = sub; e < d; e += G) { const float t = xr[e] - mean; q = fmaf(t, t, q); }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, G);
+    const float rstd = 1.0f / sqrtf(q / (float)d + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = sub; e < d; e += G) {
+        const float xh = (xr[e] - mean) * rstd;
+        const float g = gr[e] * (gamma ? gamma[e] : 1.0f);
+        s1 += g;
+        s2 = fmaf(g, xh, s2);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, G); s2 += __shfl_xor(s2, o, G); }
+    const float m1 = s1 / (float)d, m2 = s2 / (float)d;
+    for (int e = sub; e < d; e += G) {
+        const float xh = (xr[e] - mean) * rstd;
+        const float g = gr[e] * (gamma ? gamma[e] : 1.0f);
+        dx[row * d + e] = rstd * (g - m1 - xh * m2);
+        if (dy_xhat) dy_xhat[row * d + e] = gr[e] * xh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// q[B][Sq][H*DH], k / v[B][Skv][H*DH], o / dout[B][Sq][H*DH]; key j is visible to query i iff mask_off < 0 or j <= i + mask_off.
+// Pass over queries: thread = query; the log-sum-exp of its scores (base 2) and D = dout . o are kept for the key pass;
+//   dq_i = scale * sum_j dS_ij k_j,   dS_ij = P_ij (dout_i . v_j - D_i).
+template <int DH>
+__global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                                              int H, int Sq, int Skv, float scale, int mask_off, float* dq, float* stats) {
+    __shared__ float ks[128][DH], vs[128][DH];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const bool valid = i < Sq;
+    const int ld = H * DH;
+    const int ic = valid ? i : Sq - 1;
+    const int64_t qoff = ((int64_t)b * Sq + ic) * ld + h * DH;
+    float qs[DH], go[DH], dqa[DH];
+    float D = 0.f;
+#pragma unroll
+    for (int e = 0; e < DH; ++e) {
+        qs[e] = q[qoff + e] * (scale * kLog2e);
+        go[e] = dout[qoff + e];
+        D = fmaf(go[e], o[qoff + e], D);
+        dqa[e] = 0.f;
+    }
+    const int last = mask_off < 0 ? Skv - 1 : min(Skv - 1, ic + mask_off);       // last visible key of this query
+    const float* kb = k + (int64_t)b * Skv * ld + h * DH;
+    const float* vb = v + (int64_t)b * Skv * ld + h * DH;
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < Skv; j0 += 128) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 128 * DH; idx += 128) {
+            const int jj = idx / DH, e = idx % DH;
+            ks[jj][e] = j0 + jj < Skv ? kb[(int64_t)(j0 + jj) * ld + e] : 0.f;
+        }
+        __syncthreads();
+        const int jn = min(128, last - j0 + 1);
+        for (int jj = 0; jj < jn; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) s = fmaf(qs[e], ks[jj][e], s);
+            const float mn = fmaxf(m, s);
+            l = l * exp2f(m - mn) + exp2f(s - mn);
+            m = mn;
+        }
+    }
+    const float lse = m + log2f(l);
+    for (int j0 = 0; j0 < Skv; j0 += 128) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 128 * DH; idx += 128) {
+            const int jj = idx / DH, e = idx % DH;
+            const bool ok = j0 + jj < Skv;
+            ks[jj][e] = ok ? kb[(int64_t)(j0 + jj) * ld + e] : 0.f;
+            vs[jj][e] = ok ? vb[(int64_t)(j0 + jj) * ld + e] : 0.f;
+        }
+        __syncthreads();
+        const int jn = min(128, last - j0 + 1);
+        for (int jj = 0; jj < jn; ++jj) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { s = fmaf(qs[e], ks[jj][e], s); dp = fmaf(go[e], vs[jj][e], dp); }
+            const float ds = exp2f(s - lse) * (dp - D);
+#pragma unroll
+            for (int e = 0; e < DH; ++e) dqa[e] = fmaf(ds, ks[jj][e], dqa[e]);
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < DH; ++e) dq[qoff + e] = dqa[e] * scale;
+    float* st = stats + (((int64_t)b * H + h) * Sq + i) * 2;
+    st[0] = lse;
+    st[1] = D;
+}
+
+// Pass over keys: thread = key;  dv_j = sum_i P_ij dout_i,   dk_j = scale * sum_i dS_ij q_i.
+template <int DH>
+__global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const float* k, const float* v, const float* dout, const float* stats,
+                                                            int H, int Sq, int Skv, float scale, int mask_off, float* dk, float* dv) {
+    __shared__ float qsh[128][DH], gsh[128][DH], ssh[128][2];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    const bool valid = j < Skv;
+    const int ld = H * DH;
+    const int jc = valid ? j : Skv - 1;
+    const int64_t koff = ((int64_t)b * Skv + jc) * ld + h * DH;
+    float kk[DH], vv[DH], dka[DH], dva[DH];
+#pragma unroll
+    for (int e = 0; e < DH; ++e) { kk[e] = k[koff + e]; vv[e] = v[koff + e]; dka[e] = 0.f; dva[e] = 0.f; }
+    const int first = mask_off < 0 ? 0 : max(0, jc - mask_off);                // first query that sees this key
+    const float* qb = q + (int64_t)b * Sq * ld + h * DH;
+    const float* gb = dout + (int64_t)b * Sq * ld + h * DH;
+    const float* sb = stats + ((int64_t)b * H + h) * Sq * 2;
+    for (int i0 = 0; i0 < Sq; i0 += 128) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 128 * DH; idx += 128) {
+            const int ii = idx / DH, e = idx % DH;
+            const bool ok = i0 + ii < Sq;
+            qsh[ii][e] = ok ? qb[(int64_t)(i0 + ii) * ld + e] * (scale * kLog2e) : 0.f;
+            gsh[ii][e] = ok ? gb[(int64_t)(i0 + ii) * ld + e] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < 256; idx += 128) {
+            const int ii = idx >> 1;
+            ssh[ii][idx & 1] = i0 + ii < Sq ? sb[(int64_t)(i0 + ii) * 2 + (idx & 1)] : 0.f;
+        }
+        __syncthreads();
+        const int in = min(128, Sq - i0);
+        for (int ii = max(0, first - i0); ii < in; ++ii) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { s = fmaf(qsh[ii][e], kk[e], s); dp = fmaf(gsh[ii][e], vv[e], dp); }
+            const float p = exp2f(s - ssh[ii][0]);
+            const float ds = p * (dp - ssh[ii][1]);
+#pragma unroll
+            for (int e = 0; e < DH; ++e) { dva[e] = fmaf(p, gsh[ii][e], dva[e]); dka[e] = fmaf(ds, qsh[ii][e], dka[e]); }
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int e = 0; e < DH; ++e) { dk[koff + e] = dka[e] * (1.0f / kLog2e); dv[koff + e] = dva[e]; }
+}
+
+unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// rows per chunk (a multiple of 32) and number of chunks for a reduction over M rows
+void chunking(int64_t M, int64_t* rows_per_chunk, int* n_chunks) {
+    int64_t rpc = (M + 511) / 512;
+    rpc = ((rpc + 31) / 32) * 32;
+    if (rpc < 256) rpc = 256;
+    *rows_per_chunk = rpc;
+    *n_chunks = (int)((M + rpc - 1) / rpc);
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+ADX_API int adx_op_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return fail(ADX_EINVAL, "add: null pointer or empty shape");
+    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return done(hipGetLastError(), "add");
+}
+
+ADX_API int adx_op_gelu(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return fail(ADX_EINVAL, "gelu: null pointer or empty shape");
+    hipLaunchKernelGGL(gelu_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return done(hipGetLastError(), "gelu");
+}
+
+ADX_API int adx_op_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    if (!x || !dy || !dx || n <= 0) return fail(ADX_EINVAL, "gelu_bwd: null pointer or empty shape");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+    return done(hipGetLastError(), "gelu_bwd");
+}
+
+ADX_API int adx_op_weighted_mse_bwd(const float* out, const float* target, const int64_t* t, const float* weight, const float* upstream,
+                                    float* dout, int n_rows, int row_len, void* stream) {
+    if (!out || !target || !t || !weight || !dout) return fail(ADX_EINVAL, "weighted_mse_bwd: null pointer");
+    if (n_rows <= 0 || row_len <= 0) return fail(ADX_EINVAL, "weighted_mse_bwd: empty shape");
+    const int64_t total = (int64_t)n_rows * row_len;
+    hipLaunchKernelGGL(weighted_mse_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, out, target, t, weight, upstream,
+                       dout, total, row_len, 1.0f / (float)total);
+    return done(hipGetLastError(), "weighted_mse_bwd");
+}
+
+ADX_API int adx_op_transpose(const float* x, float* y, int rows, int cols, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0) return fail(ADX_EINVAL, "transpose: null pointer or empty shape");
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols);
+    return done(hipGetLastError(), "transpose");
+}
+
+ADX_API size_t adx_reduce_ws_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < 0) return 0;
+    int64_t rpc; int nc;
+    chunking(M, &rpc, &nc);
+    return (size_t)nc * ((size_t)N * (K > 0 ? K : 1) + (K > 0 ? N : 0)) * sizeof(float);
+}
+
+ADX_API int adx_op_colsum(const float* x, int64_t M, int N, float* out, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !out || !workspace) return fail(ADX_EINVAL, "colsum: null pointer");
+    if (M <= 0 || N <= 0) return fail(ADX_EINVAL, "colsum: empty shape");
+    if (workspace_bytes < adx_reduce_ws_bytes(M, N, 0)) return fail(ADX_EINVAL, "colsum: workspace smaller than adx_reduce_ws_bytes(M, N, 0)");
+    int64_t rpc; int nc;
+    chunking(M, &rpc, &nc);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nc), dim3(256), 0, (hipStream_t)stream, x, M, N, rpc, partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, (hipStream_t)stream, partial, nc, (int64_t)N, (int64_t)N, out,
+                       accumulate);
+    return done(hipGetLastError(), "colsum");
+}
+
+ADX_API int adx_op_linear_wgrad(const float* dy, const float* x, int64_t M, int N, int K, float* dw, float* db, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !dw || !workspace) return fail(ADX_EINVAL, "linear_wgrad: null pointer");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(ADX_EINVAL, "linear_wgrad: empty shape");
+    if (workspace_bytes < adx_reduce_ws_bytes(M, N, K)) return fail(ADX_EINVAL, "linear_wgrad: workspace smaller than adx_reduce_ws_bytes(M, N, K)");
+    int64_t rpc; int nc;
+    chunking(M, &rpc, &nc);
+    float* partial = static_cast<float*>(workspace);
+    const int64_t stride = (int64_t)N * K + N;
+    const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(tiles, nc), dim3(256), 0, (hipStream_t)stream, dy, x, M, N, K, rpc, partial, stride, db ? 1 : 0);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, (hipStream_t)stream, partial, nc, stride,
+                       (int64_t)N * K, dw, accumulate);
+    if (db)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, (hipStream_t)stream, partial + (int64_t)N * K, nc, stride,
+                           (int64_t)N, db, accumulate);
+    return done(hipGetLastError(), "linear_wgrad");
+}
+
+ADX_API int adx_op_layernorm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int d, float eps, float* dx, float* dy_xhat,
+                                 void* stream) {
+    if (!x || !dy || !dx) return fail(ADX_EINVAL, "layernorm_bwd: null pointer");
+    if (rows <= 0 || d <= 0) return fail(ADX_EINVAL, "layernorm_bwd: empty shape");
+    if (d <= 32)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, rows, d, eps,
+                           dx, dy_xhat);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, rows, d, eps,
+                           dx, dy_xhat);
+    return done(hipGetLastError(), "layernorm_bwd");
+}
+
+ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H, int Sq, int Skv,
+                                 int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, void* stream) {
+    if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !stats) return fail(ADX_EINVAL, "attention_bwd: null pointer");
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_bwd: empty shape");
+    if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_bwd: batch or head count above 65535");
+    const dim3 gq((Sq + 127) / 128, H, B), gk((Skv + 127) / 128, H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define ADX_ATTN_BWD(DH)                                                                                                                   \
+    case DH:                                                                                                                               \
+        hipLaunchKernelGGL(attn_bwd_query_kernel<DH>, gq, dim3(128), 0, s, q, k, v, o, dout, H, Sq, Skv, scale, mask_off, dq, stats);      \
+        hipLaunchKernelGGL(attn_bwd_key_kernel<DH>, gk, dim3(128), 0, s, q, k, v, dout, stats, H, Sq, Skv, scale, mask_off, dk, dv);       \
+        break;
+    switch (dh) {
+        ADX_ATTN_BWD(4)
+        ADX_ATTN_BWD(8)
+        ADX_ATTN_BWD(16)
+        default: return fail(ADX_EINVAL, "attention_bwd: head width must be 4, 8 or 16");
+    }
+#undef ADX_ATTN_BWD
+    return done(hipGetLastError(), "attention_bwd");
+}

@@ -160,6 +160,7 @@ class Transformer(nn.Module):
             raise NotImplementedError("n_prior_steps must equal horizon")
         self.precision = precision
         self.elide = int(elide)
+        self._n_head = int(n_head)
         self._engine: Optional[Engine] = None
         self._engine_key = None
 
@@ -258,11 +259,47 @@ class DiffusionWrapper(nn.Module):
         return eng.sample_a(maps, _lib.f32c(prior["transition_info"]), _lib.f32c(prior["trajectory_prior"]),
                             _lib.f32c(noise) if noise is not None else None, self.flags(), trace=trace)
 
-    @torch.no_grad()
     def p_losses(self, prior: Dict[str, torch.Tensor], x_start: torch.Tensor, t: Optional[torch.Tensor] = None,
                  noise: Optional[torch.Tensor] = None, return_rows: bool = False):
-        """Forward-only value of the training loss (TrajRefiner.py:417-452): normalise, q_sample at a random timestep per row,
-        one denoiser call, min-SNR weighted mean squared error.  ``t`` (B,) int64 and ``noise`` like ``x_start`` may be given."""
+        """The training loss (TrajRefiner.py:417-452): normalise, q_sample at a random timestep per row, one denoiser call,
+        min-SNR weighted mean squared error.  ``t`` (B,) int64 and ``noise`` like ``x_start`` may be given.  With gradients
+        enabled and trainable parameters the result is differentiable (fp32 training path, ``train.py``): ``loss.backward()``
+        fills the denoiser's ``.grad``s as the reference's autograd does; otherwise (``torch.no_grad()``, the evaluation
+        entry) only the value is computed, on the sampling engine."""
+        from . import train
+        if train.wants_grad(self.model):
+            return self._p_losses_grad(prior, x_start, t, noise, return_rows)
+        with torch.no_grad():
+            return self._p_losses_value(prior, x_start, t, noise, return_rows)
+
+    def _p_losses_grad(self, prior, x_start, t, noise, return_rows):
+        from . import ops, train
+        x0 = _lib.f32c(x_start)
+        tran, pri = prior["transition_info"], _lib.f32c(prior["trajectory_prior"])
+        if self.auto_normalize_data:
+            x0, pri = ops.normalize(x0), ops.normalize(pri)
+            if tran.requires_grad:           # init_x reaches the loss through the transition rows: keep this affine map in autograd
+                C = tran.shape[-1]
+                scale = torch.tensor([1 / 25.0, 1 / 5.0, 1.0, 1.0][:C], device=tran.device, dtype=torch.float32)
+                shift = torch.tensor([-1.0, 0.0, 0.0, 0.0][:C], device=tran.device, dtype=torch.float32)
+                tran = tran.to(torch.float32) * scale + shift
+            else:
+                tran = ops.normalize(_lib.f32c(tran))
+        B = x0.shape[0]
+        if t is None:
+            t = torch.randint(0, self.timesteps, (B,), device=x0.device)
+        t = t.to(device=x0.device, dtype=torch.int64).contiguous()
+        noise = _lib.f32c(noise if noise is not None else torch.randn_like(x0))
+        x, v = ops.q_sample(x0, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, want_v=self.objective == "pred_v")
+        cond = dict(maps_info=prior.get("maps_info"), transition_info=tran, trajectory_prior=pri)
+        model_out = train.denoise_with_grad(self.model, x, t, cond, self.model._n_head)
+        target = {"pred_noise": noise, "pred_x0": x0, "pred_v": v}[self.objective]
+        mean = train.WeightedMSE.apply(model_out, target, t, self.loss_weight)
+        if return_rows:
+            return mean, ops.weighted_mse(model_out.detach(), target, t, self.loss_weight)[0]
+        return mean
+
+    def _p_losses_value(self, prior, x_start, t, noise, return_rows):
         from . import ops
         x0 = _lib.f32c(x_start)
         tran, pri = _lib.f32c(prior["transition_info"]), _lib.f32c(prior["trajectory_prior"])
@@ -310,7 +347,6 @@ class TrajectoryRefiner(nn.Module):
         condition = {"maps_info": maps_info, "transition_info": transition_info, "trajectory_prior": trajectory_prior}
         return self.diffusion.sample(condition, label, noise=noise, **kwargs)
 
-    @torch.no_grad()
     def forward(self, label, transition_info, trajectory_prior, maps_info, t: Optional[torch.Tensor] = None,
                 noise: Optional[torch.Tensor] = None):
         """-> (loss, logits): the diffusion loss of one chunk times ``trajectory_loss_rescale`` and, as in the reference
@@ -372,7 +408,6 @@ class DiffusionAugmentation(nn.Module):
                               _lib.f32c(noise) if noise is not None else None, self.frame_stack, wrapper.flags(), out=out)
         return {"traj_logits": traj}
 
-    @torch.no_grad()
     def forward(self, return_dict=None, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
         """The evaluation-time value of the training objective (DiffusionAugmentation.py:75-135), forward only: per chunk
         one diffusion loss of the label chunk (label minus prior with ``residual``) conditioned on the prior chunk and on the

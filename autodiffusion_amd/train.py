@@ -1,0 +1,339 @@
+"""Training path of the refiner: the denoiser's forward with its activations kept, and the backward that turns the loss
+gradient into parameter gradients -- what ``loss.backward()`` does in the reference, where the loss of
+``DiffusionWrapper.p_losses`` (models/diffusion_loss/TrajRefiner.py:417-452) is differentiated by torch autograd through
+``Transformer.forward`` (models/diffusion_loss/transformer.py:189-273).
+
+Every arithmetic step is a libadx kernel (fp32): the forward operators of ``ops`` and the backward operators declared in
+``include/adx.h`` (``adx_op_linear_wgrad``, ``adx_op_layernorm_bwd``, ``adx_op_attention_bwd``, ``adx_op_gelu_bwd``,
+``adx_op_colsum``, ``adx_op_weighted_mse_bwd`` ...).  torch is used for memory only (concatenation, slicing, broadcasting
+copies, zero-filled gradient buffers) and for the autograd bookkeeping: ``DenoiserA`` / ``WeightedMSE`` are
+``torch.autograd.Function``s, so ``loss.backward()`` and any torch optimizer work on the wrapper classes unchanged.
+
+There is no dropout (the reference's ``nn.Dropout(0.1)`` layers are active under ``.train()``; this path corresponds to the
+reference with its denoiser in ``.eval()``, the configuration the gradient fixture was recorded in).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, current_stream, f32c, ptr
+
+
+# ------------------------------------------------------------------------------------------------ operator wrappers
+def _scratch(M: int, N: int, K: int, device) -> torch.Tensor:
+    n = int(_lib.load().adx_reduce_ws_bytes(int(M), int(N), int(K)))
+    return torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a, b = f32c(a), f32c(b)
+    if a.shape != b.shape:
+        raise ValueError("add: shapes differ")
+    out = torch.empty_like(a)
+    check(_lib.load().adx_op_add(ptr(a), ptr(b), ptr(out), a.numel(), current_stream()), "add")
+    return out
+
+
+def transpose(w: torch.Tensor) -> torch.Tensor:
+    w = f32c(w)
+    rows, cols = w.shape
+    out = torch.empty(cols, rows, device=w.device, dtype=torch.float32)
+    check(_lib.load().adx_op_transpose(ptr(w), ptr(out), rows, cols, current_stream()), "transpose")
+    return out
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    x = f32c(x)
+    y = torch.empty_like(x)
+    check(_lib.load().adx_op_gelu(ptr(x), ptr(y), x.numel(), current_stream()), "gelu")
+    return y
+
+
+def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    x, dy = f32c(x), f32c(dy)
+    dx = torch.empty_like(x)
+    check(_lib.load().adx_op_gelu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), current_stream()), "gelu_bwd")
+    return dx
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], accumulate: bool = True) -> None:
+    """dw (N, K) (+)= dy^T x, db (N,) (+)= column sums of dy; dy (..., N), x (..., K).  dw / db are written in place."""
+    dy, x = f32c(dy), f32c(x)
+    N, K = dy.shape[-1], x.shape[-1]
+    M = dy.numel() // N
+    if x.numel() // K != M or tuple(dw.shape) != (N, K) or (db is not None and db.numel() != N):
+        raise ValueError("linear_wgrad: operand shapes do not match")
+    ws = _scratch(M, N, K, dy.device)
+    check(_lib.load().adx_op_linear_wgrad(ptr(dy), ptr(x), M, N, K, ptr(dw), ptr(db), int(accumulate), ptr(ws), ws.numel(), current_stream()),
+          "linear_wgrad")
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = True) -> None:
+    """out (N,) (+)= column sums of x viewed as (M, N) with N = out.numel()."""
+    x = f32c(x)
+    N = out.numel()
+    M = x.numel() // N
+    if M * N != x.numel():
+        raise ValueError("colsum: operand shapes do not match")
+    ws = _scratch(M, N, 0, x.device)
+    check(_lib.load().adx_op_colsum(ptr(x), M, N, ptr(out), int(accumulate), ptr(ws), ws.numel(), current_stream()), "colsum")
+
+
+def layernorm_bwd(x: torch.Tensor, gamma: Optional[torch.Tensor], dy: torch.Tensor, eps: float = 1e-5, want_dy_xhat: bool = True):
+    """-> (dx, dy * xhat or None) for y = LayerNorm(x) * gamma + beta over the last axis."""
+    x, dy = f32c(x), f32c(dy)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dx = torch.empty_like(x)
+    dyx = torch.empty_like(x) if want_dy_xhat else None
+    check(_lib.load().adx_op_layernorm_bwd(ptr(x), ptr(f32c(gamma)) if gamma is not None else None, ptr(dy), rows, d, float(eps), ptr(dx),
+                                           ptr(dyx), current_stream()), "layernorm_bwd")
+    return dx, dyx
+
+
+def attention_bwd(q, k, v, o, dout, n_head: int, scale: Optional[float] = None, mask_off: int = -1):
+    """Backward of ``ops.attention`` (same layouts, same mask rule) -> (dq, dk, dv)."""
+    q, k, v, o, dout = f32c(q), f32c(k), f32c(v), f32c(o), f32c(dout)
+    B, Sq, Skv = q.shape[0], q.shape[1], k.shape[1]
+    dh = q.shape[2] // n_head
+    if v.shape[2] != q.shape[2] or o.shape != q.shape or dout.shape != q.shape:
+        raise ValueError("attention_bwd: value width must equal the key width")
+    if scale is None:
+        scale = dh ** -0.5
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    stats = torch.empty(B, n_head, Sq, 2, device=q.device, dtype=torch.float32)
+    check(_lib.load().adx_op_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), B, n_head, Sq, Skv, dh, float(scale), int(mask_off),
+                                           ptr(dq), ptr(dk), ptr(dv), ptr(stats), current_stream()), "attention_bwd")
+    return dq, dk, dv
+
+
+def weighted_mse_bwd(out, target, t, weight, upstream: Optional[torch.Tensor]) -> torch.Tensor:
+    out, target = f32c(out), f32c(target)
+    t = t.to(device=out.device, dtype=torch.int64).contiguous()
+    w = f32c(weight).to(out.device)
+    up = f32c(upstream).reshape(1) if upstream is not None else None
+    n_rows = out.shape[0]
+    dout = torch.empty_like(out)
+    check(_lib.load().adx_op_weighted_mse_bwd(ptr(out), ptr(target), ptr(t), ptr(w), ptr(up), ptr(dout), n_rows, out.numel() // n_rows,
+                                              current_stream()), "weighted_mse_bwd")
+    return dout
+
+
+# ------------------------------------------------------------------------------------------------ the network, forward and backward
+class _Grads:
+    """Gradient buffers by parameter name, zero-filled on first use; the kernels accumulate into them."""
+
+    def __init__(self, params: Dict[str, torch.Tensor]):
+        self.params = params
+        self.g: Dict[str, torch.Tensor] = {}
+
+    def of(self, name: str) -> torch.Tensor:
+        if name not in self.g:
+            self.g[name] = torch.zeros_like(self.params[name], dtype=torch.float32, memory_format=torch.contiguous_format)
+        return self.g[name]
+
+
+def _lin(P, x, prefix: str, rows: Optional[slice] = None):
+    w, b = P[prefix + "weight"], P[prefix + "bias"]
+    if rows is not None:
+        w, b = w[rows], b[rows]
+    return ops.linear(x, f32c(w), f32c(b))
+
+
+def _lin_bwd(P, G: _Grads, dy, x, prefix: str, rows: Optional[slice] = None, need_dx: bool = True):
+    """Accumulates dW / db of ``y = x W[rows]^T + b[rows]`` and returns dx = dy W[rows] (None when not needed)."""
+    gw, gb = G.of(prefix + "weight"), G.of(prefix + "bias")
+    w = P[prefix + "weight"]
+    if rows is not None:
+        gw, gb, w = gw[rows], gb[rows], w[rows]
+    linear_wgrad(dy, x, gw, gb, accumulate=True)
+    if not need_dx:
+        return None
+    return ops.linear(dy, transpose(w))
+
+
+def _ln_bwd(P, G: _Grads, x, dy, prefix: str):
+    dx, dyx = layernorm_bwd(x, P[prefix + "weight"], dy, 1e-5)
+    colsum(dyx, G.of(prefix + "weight"))
+    colsum(dy, G.of(prefix + "bias"))
+    return dx
+
+
+def _mha(P, prefix: str, xq, xkv, n_head: int, mask_off: int):
+    d = xq.shape[-1]
+    q = _lin(P, xq, prefix + "in_proj_", slice(0, d))
+    k = _lin(P, xkv, prefix + "in_proj_", slice(d, 2 * d))
+    v = _lin(P, xkv, prefix + "in_proj_", slice(2 * d, 3 * d))
+    o = ops.attention(q, k, v, n_head, mask_off=mask_off)
+    return _lin(P, o, prefix + "out_proj."), (q, k, v, o)
+
+
+def _mha_bwd(P, G, prefix: str, xq, xkv, saved, da, n_head: int, mask_off: int):
+    """-> (d xq, d xkv) of ``out_proj(attention(q(xq), k(xkv), v(xkv)))``."""
+    q, k, v, o = saved
+    d = xq.shape[-1]
+    do = _lin_bwd(P, G, da, o, prefix + "out_proj.")
+    dq, dk, dv = attention_bwd(q, k, v, o, do, n_head, mask_off=mask_off)
+    dxq = _lin_bwd(P, G, dq, xq, prefix + "in_proj_", slice(0, d))
+    dxkv = add(_lin_bwd(P, G, dk, xkv, prefix + "in_proj_", slice(d, 2 * d)), _lin_bwd(P, G, dv, xkv, prefix + "in_proj_", slice(2 * d, 3 * d)))
+    return dxq, dxkv
+
+
+def _ffn(P, prefix: str, h):
+    pre = _lin(P, h, prefix + "linear1.")
+    act = gelu(pre)
+    return _lin(P, act, prefix + "linear2."), (pre, act)
+
+
+def _ffn_bwd(P, G, prefix: str, h, saved, df):
+    pre, act = saved
+    dact = _lin_bwd(P, G, df, act, prefix + "linear2.")
+    return _lin_bwd(P, G, gelu_bwd(pre, dact), h, prefix + "linear1.")
+
+
+def _norm(P, prefix: str, x):
+    return ops.layernorm(x, P[prefix + "weight"], P[prefix + "bias"], eps=1e-5)
+
+
+def denoiser_forward(P: Dict[str, torch.Tensor], x, t, maps, transition, prior, n_head: int, n_enc: int, n_dec: int):
+    """transformer.py:189-273 with every intermediate a backward needs kept.  -> (out (B, T, C), tape)."""
+    d = P["input_emb.weight"].shape[0]
+    B, T = x.shape[0], x.shape[1]
+    tape: Dict[str, object] = {"x": x, "maps": maps, "transition": transition, "prior": prior}
+    parts = [ops.timestep_embedding(t, d)[:, None, :]]
+    if maps is not None:
+        parts.append(_lin(P, maps, "cond_obs_emb."))
+    parts += [_lin(P, transition, "prior_z_emb."), _lin(P, prior, "prior_z_emb.")]
+    c = torch.cat(parts, dim=1)
+    S = c.shape[1]
+    c = add(c, P["cond_pos_emb"][:, :S].expand(B, S, d).contiguous())
+    enc = []
+    for i in range(n_enc):
+        p = f"encoder.layers.{i}."
+        h1 = _norm(P, p + "norm1.", c)
+        a, sa = _mha(P, p + "self_attn.", h1, h1, n_head, -1)
+        c1 = add(c, a)
+        h2 = _norm(P, p + "norm2.", c1)
+        f, sf = _ffn(P, p, h2)
+        enc.append((c, h1, sa, c1, h2, sf))
+        c = add(c1, f)
+    memory = c
+    y = add(_lin(P, x, "input_emb."), P["pos_emb"][:, :T].expand(B, T, d).contiguous())
+    dec = []
+    for i in range(n_dec):
+        p = f"decoder.layers.{i}."
+        h1 = _norm(P, p + "norm1.", y)
+        a, sa = _mha(P, p + "self_attn.", h1, h1, n_head, 0)
+        y1 = add(y, a)
+        h2 = _norm(P, p + "norm2.", y1)
+        m, sm = _mha(P, p + "multihead_attn.", h2, memory, n_head, 1)
+        y2 = add(y1, m)
+        h3 = _norm(P, p + "norm3.", y2)
+        f, sf = _ffn(P, p, h3)
+        dec.append((y, h1, sa, y1, h2, sm, y2, h3, sf))
+        y = add(y2, f)
+    hn = _norm(P, "ln_f.", y)
+    out = _lin(P, hn, "head.")
+    tape.update(enc=enc, dec=dec, memory=memory, y=y, hn=hn, S=S)
+    return out, tape
+
+
+def denoiser_backward(P: Dict[str, torch.Tensor], tape, dout, n_head: int, want_transition_grad: bool = False):
+    """-> ({parameter name: gradient}, d transition or None)."""
+    G = _Grads(P)
+    x, maps, transition, prior = tape["x"], tape["maps"], tape["transition"], tape["prior"]
+    B, T = x.shape[0], x.shape[1]
+    d = P["input_emb.weight"].shape[0]
+    S = tape["S"]
+    dy = _ln_bwd(P, G, tape["y"], _lin_bwd(P, G, f32c(dout), tape["hn"], "head."), "ln_f.")
+    dmem = None
+    for i in reversed(range(len(tape["dec"]))):
+        p = f"decoder.layers.{i}."
+        y, h1, sa, y1, h2, sm, y2, h3, sf = tape["dec"][i]
+        dy2 = add(dy, _ln_bwd(P, G, y2, _ffn_bwd(P, G, p, h3, sf, dy), p + "norm3."))
+        dh2, dm = _mha_bwd(P, G, p + "multihead_attn.", h2, tape["memory"], sm, dy2, n_head, 1)
+        dmem = dm if dmem is None else add(dmem, dm)
+        dy1 = add(dy2, _ln_bwd(P, G, y1, dh2, p + "norm2."))
+        dq, dkv = _mha_bwd(P, G, p + "self_attn.", h1, h1, sa, dy1, n_head, 0)
+        dy = add(dy1, _ln_bwd(P, G, y, add(dq, dkv), p + "norm1."))
+    colsum(dy, _slice_rows(G.of("pos_emb"), T))
+    _lin_bwd(P, G, dy, x, "input_emb.", need_dx=False)
+    dc = dmem
+    for i in reversed(range(len(tape["enc"]))):
+        p = f"encoder.layers.{i}."
+        c, h1, sa, c1, h2, sf = tape["enc"][i]
+        dc1 = add(dc, _ln_bwd(P, G, c1, _ffn_bwd(P, G, p, h2, sf, dc), p + "norm2."))
+        dq, dkv = _mha_bwd(P, G, p + "self_attn.", h1, h1, sa, dc1, n_head, -1)
+        dc = add(dc1, _ln_bwd(P, G, c, add(dq, dkv), p + "norm1."))
+    colsum(dc, _slice_rows(G.of("cond_pos_emb"), S))
+    at = 1
+    if maps is not None:
+        n_maps = maps.shape[1]
+        _lin_bwd(P, G, dc[:, at:at + n_maps].contiguous(), maps, "cond_obs_emb.", need_dx=False)
+        at += n_maps
+    n_tr = transition.shape[1]
+    d_tr = _lin_bwd(P, G, dc[:, at:at + n_tr].contiguous(), transition, "prior_z_emb.", need_dx=want_transition_grad)
+    at += n_tr
+    _lin_bwd(P, G, dc[:, at:at + prior.shape[1]].contiguous(), prior, "prior_z_emb.", need_dx=False)
+    return G.g, d_tr
+
+
+def _slice_rows(g: torch.Tensor, n: int) -> torch.Tensor:
+    """The first n rows of a (1, L, d) table as a flat view (contiguous: the table has one leading row)."""
+    return g[0, :n].reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ autograd glue
+class DenoiserA(torch.autograd.Function):
+    """``Transformer.forward`` as a differentiable function of its parameters (and of ``transition_info``)."""
+
+    @staticmethod
+    def forward(ctx, meta, x, t, maps, transition, prior, *params):
+        names, n_head, n_enc, n_dec = meta
+        P = {n: p.detach() for n, p in zip(names, params)}
+        out, tape = denoiser_forward(P, f32c(x), t, f32c(maps) if maps is not None else None, f32c(transition), f32c(prior), n_head, n_enc, n_dec)
+        ctx.meta, ctx.P, ctx.tape = meta, P, tape
+        ctx.want_tr = bool(ctx.needs_input_grad[4])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        names, n_head, _, _ = ctx.meta
+        grads, d_tr = denoiser_backward(ctx.P, ctx.tape, dout.contiguous(), n_head, ctx.want_tr)
+        ctx.tape = None
+        return (None, None, None, None, d_tr, None) + tuple(grads.get(n) for n in names)
+
+
+class WeightedMSE(torch.autograd.Function):
+    """mean_b( weight[t_b] * mean_e (out - target)^2 ): the reduction of p_losses (TrajRefiner.py:448-452)."""
+
+    @staticmethod
+    def forward(ctx, out, target, t, weight):
+        rows, mean = ops.weighted_mse(out, target, t, weight)
+        ctx.save_for_backward(out, target, t, weight)
+        return mean
+
+    @staticmethod
+    def backward(ctx, dmean):
+        out, target, t, weight = ctx.saved_tensors
+        return weighted_mse_bwd(out, target, t, weight, dmean), None, None, None
+
+
+def trainable_names(module: torch.nn.Module) -> List[str]:
+    return [n for n, _ in module.named_parameters()]
+
+
+def denoise_with_grad(module: torch.nn.Module, x, t, condition: Dict[str, torch.Tensor], n_head: int) -> torch.Tensor:
+    """Differentiable call of a ``refiner.Transformer``: the result carries a grad_fn whose backward fills the module's ``.grad``s."""
+    names = trainable_names(module)
+    params = [p for _, p in module.named_parameters()]
+    n_enc, n_dec = len(module.encoder.layers), len(module.decoder.layers)
+    maps = condition.get("maps_info") if module.map_cond else None
+    return DenoiserA.apply((tuple(names), n_head, n_enc, n_dec), x, t, maps, condition["transition_info"], condition["trajectory_prior"], *params)
+
+
+def wants_grad(module: torch.nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())

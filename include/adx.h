@@ -222,6 +222,43 @@ int adx_op_q_sample(const float* x0, const float* noise, const int64_t* t, const
 int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows,
                         float* loss_mean, int n_rows, int row_len, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Backward operators of the refiner's training path (fp32).  The reference differentiates its loss with torch autograd
+ * (loss.backward() on TrajRefiner.py:417-452 over transformer.py:189-273); each entry point below is the backward of one forward
+ * operator above.  dX of a Linear is adx_op_linear on the transposed weight (adx_op_transpose).  Reductions over rows are
+ * summed per row chunk and combined in a fixed order: results do not depend on launch timing.
+ * ------------------------------------------------------------------------------------------ */
+int adx_op_add(const float* a, const float* b, float* out, int64_t n, void* stream);              /* residual adds, gradient sums */
+int adx_op_transpose(const float* x, float* y, int rows, int cols, void* stream);                 /* y[cols][rows] = x^T */
+/* F.gelu (erf form; activation of nn.TransformerEncoder/DecoderLayer, transformer.py:69-102) and its derivative:
+ * dx = dy (Phi(x) + x phi(x)) with x the pre-activation. */
+int adx_op_gelu(const float* x, float* y, int64_t n, void* stream);
+int adx_op_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* Scratch bytes of the row reductions below: adx_reduce_ws_bytes(M, N, K) for adx_op_linear_wgrad, (M, N, 0) for adx_op_colsum. */
+size_t adx_reduce_ws_bytes(int64_t M, int N, int K);
+/* nn.Linear backward, parameter side: dw[N][K] = dy[M][N]^T x[M][K], db[N] (nullable) = column sums of dy; added to the
+ * existing contents when `accumulate` is non-zero (torch accumulates into .grad). */
+int adx_op_linear_wgrad(const float* dy, const float* x, int64_t M, int N, int K, float* dw, float* db, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* out[N] (+)= column sums of x[M][N]: LayerNorm gain / bias gradients, gradients of the learned position tables (sum over
+ * the batch), bias gradients. */
+int adx_op_colsum(const float* x, int64_t M, int N, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                  void* stream);
+/* nn.LayerNorm backward: dx, and dy_xhat (nullable) = dy * (x - mean) * rstd whose column sums are the gain gradient (the
+ * bias gradient is the column sum of dy).  gamma may be NULL (no affine). */
+int adx_op_layernorm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int d, float eps, float* dx,
+                         float* dy_xhat, void* stream);
+/* Backward of adx_op_attention (same layouts and mask rule) for head widths 4, 8, 16 (dv == dh): o is the forward output,
+ * dout its gradient; stats is scratch of 2*B*H*Sq floats (log-sum-exp and dout.o per query and head).  Probabilities are
+ * recomputed, never stored. */
+int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H,
+                         int Sq, int Skv, int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats,
+                         void* stream);
+/* Gradient of adx_op_weighted_mse's loss_mean with respect to `out`, times upstream[0] (device scalar; NULL = 1):
+ * dout[b][e] = upstream * 2 weight[t[b]] (out - target) / (n_rows * row_len)   (TrajRefiner.py:448-452 under autograd). */
+int adx_op_weighted_mse_bwd(const float* out, const float* target, const int64_t* t, const float* weight,
+                            const float* upstream, float* dout, int n_rows, int row_len, void* stream);
+
 /* Per-step coefficient table of the sampler (host memory), in execution order. */
 int adx_engine_set_schedule(adx_engine* e, const adx_step_coef* steps_host, int n_steps);
 

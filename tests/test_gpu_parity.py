@@ -1044,13 +1044,19 @@ def test_forward_loss(dev, golden, tag, fs, N, obj, sched, residual):
     maps, prior = synth.maps_info(2, ISEED).to(dev), synth.trajectory_prior(2, ISEED).to(dev)
     noise = synth.noise(2, (80 // fs,), (fs, 4), NSEED + 2).to(dev)
     label = T(g["label"]).to(dev)
-    out = da(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=T(g[f"{tag}_t"]).to(dev), noise=noise)
+    with torch.no_grad():            # the evaluation entry: PlanningTrainer.prediction_step calls compute_loss under no_grad
+        out = da(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=T(g[f"{tag}_t"]).to(dev), noise=noise)
+    assert not out.loss.requires_grad
     np.testing.assert_allclose(out.loss_items.cpu().numpy(), g[f"{tag}_loss_items"], rtol=1e-3)
+    diff = da(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=T(g[f"{tag}_t"]).to(dev), noise=noise)   # gradient mode
+    assert diff.loss.requires_grad
+    np.testing.assert_allclose(diff.loss_items.detach().cpu().numpy(), g[f"{tag}_loss_items"], rtol=1e-3)
     np.testing.assert_allclose(float(out.loss), float(g[f"{tag}_loss"]), rtol=1e-3)
     assert out["logits"].shape == (2, 80, 4) and not out.logits.any() and out.pred_dict["traj_logits"] is out.logits
     assert set(out.keys()) == {"loss", "logits", "trajectory_label", "loss_items", "pred_dict"}
     # without supplied draws the loss is a fresh sample: finite, and generate() still works afterwards (eval-entry order)
-    assert bool(torch.isfinite(da(trajectory_prior=prior, maps_info=maps, trajectory_label=label).loss))
+    with torch.no_grad():
+        assert bool(torch.isfinite(da(trajectory_prior=prior, maps_info=maps, trajectory_label=label).loss))
     assert da.generate(trajectory_prior=prior, maps_info=maps)["traj_logits"].shape == (2, 80, 4)
 
 

@@ -1,0 +1,201 @@
+"""GPU parity of the refiner's training path: each backward operator (through the C ABI) against reverse-mode differentiation
+of the same operator in float64 on the CPU, the whole backward against the gradients the reference's own ``loss.backward()``
+left in its parameters (fixture G14), and the gradient that reaches ``init_x`` against the oracle's.
+
+Tolerance: 1e-3 relative (L2 norm per tensor), the per-step gate of the fp32 path; observed values are printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ISEED, NSEED, WSEED, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GATE = 1e-3
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def l2_rel(got, want):
+    got, want = torch.as_tensor(got).double().cpu(), torch.as_tensor(want).double().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from autodiffusion_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ operators
+@pytest.mark.parametrize("M,N,K", [(20, 4, 32), (20, 32, 4), (1618, 96, 32), (1000, 32, 256), (5003, 128, 32), (300000, 32, 128), (7, 33, 70)])
+def test_op_linear_wgrad(dev, M, N, K):
+    from autodiffusion_amd import train
+    g = torch.Generator().manual_seed(M + N * 3 + K)
+    dy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+    dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    dw, db = dw0.to(dev), db0.to(dev)
+    train.linear_wgrad(dy.to(dev), x.to(dev), dw, db, accumulate=True)
+    assert l2_rel(dw, dw0.double() + dy.double().T @ x.double()) < 2e-6
+    assert l2_rel(db, db0.double() + dy.double().sum(0)) < 2e-6
+    dw2 = torch.full((N, K), 7.0, device=dev)
+    train.linear_wgrad(dy.to(dev), x.to(dev), dw2, None, accumulate=False)
+    assert l2_rel(dw2, dy.double().T @ x.double()) < 2e-6
+    again = torch.empty_like(dw2)
+    train.linear_wgrad(dy.to(dev), x.to(dev), again, None, accumulate=False)
+    assert torch.equal(again, dw2)                         # fixed summation order: bit-identical re-run
+
+
+@pytest.mark.parametrize("M,N", [(2, 25888), (16, 320), (1618, 32), (100001, 32), (33, 96), (5, 700)])
+def test_op_colsum_transpose_add(dev, M, N):
+    from autodiffusion_amd import train
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g)
+    out = torch.ones(N, device=dev)
+    train.colsum(x.to(dev), out, accumulate=True)
+    assert l2_rel(out, 1.0 + x.double().sum(0)) < 2e-6
+    if M * N < 200000:
+        assert torch.equal(train.transpose(x.to(dev)).cpu(), x.T.contiguous())
+    assert torch.equal(train.add(x.to(dev), (2 * x).to(dev)).cpu(), x + 2 * x)
+
+
+def test_op_gelu_and_loss_gradient(dev):
+    from autodiffusion_amd import ops, train
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4096, generator=g) * 3).requires_grad_(True)
+    dy = torch.randn(4096, generator=g)
+    y = torch.nn.functional.gelu(x.double())
+    y.backward(dy.double())
+    assert rel_err(train.gelu(x.detach().to(dev)).cpu(), y.detach()) < 2e-6
+    assert rel_err(train.gelu_bwd(x.detach().to(dev), dy.to(dev)).cpu(), x.grad) < 2e-6
+    out, target = torch.randn(5, 10, 4, generator=g), torch.randn(5, 10, 4, generator=g)
+    t, w = torch.tensor([0, 3, 9, 3, 1]), torch.rand(10, generator=g) + 0.1
+    o = out.double().requires_grad_(True)
+    loss = (((o - target.double()) ** 2).reshape(5, -1).mean(1) * w.double()[t]).mean()
+    (loss * 1.7).backward()
+    got = train.weighted_mse_bwd(out.to(dev), target.to(dev), t.to(dev), w.to(dev), torch.tensor(1.7, device=dev))
+    assert rel_err(got.cpu(), o.grad) < 2e-6
+    assert abs(float(ops.weighted_mse(out.to(dev), target.to(dev), t.to(dev), w.to(dev))[1]) - float(loss.detach())) < 1e-6 * abs(float(loss.detach()))
+
+
+@pytest.mark.parametrize("rows,d", [(1618, 32), (20, 32), (77, 128), (5, 1024), (9, 24)])
+def test_op_layernorm_bwd(dev, rows, d):
+    from autodiffusion_amd import train
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).double().requires_grad_(True)
+    gamma = (torch.randn(d, generator=g) * 0.5 + 1).double().requires_grad_(True)
+    beta = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(rows, d, generator=g)
+    torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5).backward(dy.double())
+    dx, dyx = train.layernorm_bwd(x.detach().float().to(dev), gamma.detach().float().to(dev), dy.to(dev), 1e-5)
+    assert l2_rel(dx, x.grad) < 5e-6
+    assert l2_rel(dyx.double().sum(0), gamma.grad) < 5e-6
+    dx0, none = train.layernorm_bwd(x.detach().float().to(dev), None, dy.to(dev), 1e-5, want_dy_xhat=False)
+    x2 = x.detach().clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(x2, (d,), None, None, 1e-5).backward(dy.double())
+    assert none is None and l2_rel(dx0, x2.grad) < 5e-6
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,dh,mask_off", [(2, 8, 809, 809, 4, -1), (3, 8, 10, 10, 4, 0), (3, 8, 10, 809, 4, 1), (2, 8, 80, 949, 4, 1),
+                                                   (1, 2, 130, 257, 8, -1), (2, 4, 33, 33, 16, 0)])
+def test_op_attention_bwd(dev, B, H, Sq, Skv, dh, mask_off):
+    from autodiffusion_amd import ops, train
+    from oracle import nets
+    g = torch.Generator().manual_seed(Sq * 3 + Skv + dh)
+    q, k, v = (torch.randn(B, S, H * dh, generator=g) for S in (Sq, Skv, Skv))
+    do = torch.randn(B, Sq, H * dh, generator=g)
+    qd, kd, vd = (a.double().requires_grad_(True) for a in (q, k, v))
+    allowed = None
+    if mask_off >= 0:
+        allowed = torch.arange(Skv)[None, :] <= torch.arange(Sq)[:, None] + mask_off
+    nets.attention(qd, kd, vd, H, allowed).backward(do.double())
+    o = ops.attention(q.to(dev), k.to(dev), v.to(dev), H, mask_off=mask_off)
+    dq, dk, dv = train.attention_bwd(q.to(dev), k.to(dev), v.to(dev), o, do.to(dev), H, mask_off=mask_off)
+    errs = [l2_rel(dq, qd.grad), l2_rel(dk, kd.grad), l2_rel(dv, vd.grad)]
+    print("attention_bwd", (B, H, Sq, Skv, dh, mask_off), ["%.1e" % e for e in errs])
+    assert max(errs) < 2e-5
+
+
+# ------------------------------------------------------------------ the whole backward
+def _refiner(dev, fs=10, N=100, obj="pred_noise", sched="cosine"):
+    from autodiffusion_amd import refiner, synth
+    tr = refiner.TrajectoryRefiner(refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective=obj, beta_schedule=sched))
+    synth.fill_module_(tr, WSEED)
+    return tr.to(dev).train()
+
+
+def _g14_inputs(dev, fs=10):
+    from autodiffusion_amd import synth
+    maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
+    label = prior + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    return dict(maps=maps.to(dev), prior=prior[:, :fs].contiguous().to(dev), label=label[:, :fs].contiguous().to(dev),
+                transition=init_x[None].expand(2, fs, 4).contiguous().to(dev), noise=synth.noise(2, (), (fs, 4), NSEED + 3).to(dev))
+
+
+def test_refiner_gradients_match_the_reference(dev, golden):
+    """loss.backward() through TrajectoryRefiner.forward on the HIP training path against the gradients the reference's own
+    backward() produced for the same weights, inputs, timesteps and noise: all 108 parameter tensors."""
+    g = golden("g14_refiner_grads")
+    tr = _refiner(dev)
+    c = _g14_inputs(dev)
+    loss, logits = tr(c["label"], c["transition"], c["prior"], c["maps"], t=T(g["t"]).to(dev), noise=c["noise"])
+    assert loss.requires_grad and not logits.any()
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-4)
+    loss.backward()
+    want = {k[len("grad."):]: v for k, v in g.items() if k.startswith("grad.")}
+    got = {n: p.grad for n, p in tr.diffusion.model.named_parameters()}
+    assert set(want) == set(got) and len(want) == 108
+    worst = max((l2_rel(got[k], v), k) for k, v in want.items())
+    print("worst gradient error %.2e at %s" % worst)
+    assert worst[0] < GATE
+    # a second backward accumulates into .grad, as torch does
+    loss2, _ = tr(c["label"], c["transition"], c["prior"], c["maps"], t=T(g["t"]).to(dev), noise=c["noise"])
+    loss2.backward()
+    assert l2_rel(tr.diffusion.model.head.weight.grad, 2 * want["head.weight"]) < GATE
+    # the value-only evaluation entry (no_grad) reports the same loss from the sampling engine
+    with torch.no_grad():
+        val, _ = tr(c["label"], c["transition"], c["prior"], c["maps"], t=T(g["t"]).to(dev), noise=c["noise"])
+    assert not val.requires_grad
+    np.testing.assert_allclose(float(val), float(g["loss"]), rtol=1e-3)
+
+
+def test_init_x_gradient_and_a_training_step(dev):
+    """DiffusionAugmentation.forward in gradient mode: the gradient reaching init_x (through the transition rows of chunk 0)
+    against reverse-mode differentiation of the oracle, and a few SGD steps on fixed draws lower the loss."""
+    from autodiffusion_amd import refiner, synth
+    from oracle import nets, sampling, schedules
+    fs, N = 10, 100
+    da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N))
+    synth.fill_module_(da.diffusion, WSEED)
+    with torch.no_grad():
+        da.init_x.copy_(synth.seeded_param("init_x", (fs, 4), WSEED))
+    da = da.to(dev).train()
+    maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
+    label = prior + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    t = torch.from_numpy(np.random.default_rng(5).integers(0, N, size=(8, 2)).astype(np.int64))
+    noise = synth.noise(2, (8,), (fs, 4), NSEED + 2)
+    out = da(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), trajectory_label=label.to(dev), t=t.to(dev), noise=noise.to(dev))
+    out.loss.backward()
+    sd = {k[len("diffusion.diffusion.model."):]: v.detach().float().cpu() for k, v in da.state_dict().items() if k.startswith("diffusion.diffusion.model.")}
+    init_x = da.init_x.detach().cpu().clone().requires_grad_(True)
+    fn = lambda x, tt, tra_n, pri_n: nets.variant_a_forward(sd, x, tt, maps, tra_n, pri_n)  # noqa: E731
+    ref_loss, _ = sampling.refiner_forward(fn, schedules.buffers("cosine", N, "pred_noise"), "pred_noise", prior, label, init_x, t, noise, fs)
+    ref_loss.backward()
+    np.testing.assert_allclose(float(out.loss), float(ref_loss), rtol=1e-4)
+    assert l2_rel(da.init_x.grad, init_x.grad) < GATE
+    # plain SGD on the same draws
+    opt = torch.optim.SGD(da.parameters(), lr=0.05)
+    first = None
+    for _ in range(4):
+        opt.zero_grad()
+        loss = da(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), trajectory_label=label.to(dev), t=t.to(dev), noise=noise.to(dev)).loss
+        loss.backward()
+        opt.step()
+        first = float(loss) if first is None else first
+    assert float(loss) < first
