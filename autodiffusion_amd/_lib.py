@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadx.so")
+LIB_PATH = os.environ.get("ADX_LIB_PATH") or os.path.join(_HERE, "libadx.so")      # ADX_LIB_PATH: another build of the library (same-box A/B timings)
 
 ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY, ACT_SILU = range(6)
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2

@@ -78,8 +78,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, int
     const int c = threadIdx.x % width, p = threadIdx.x / width;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     float s = 0.f;
-    if (p < P)
-        for (int64_t r = r0 + p; r < r1; r += P) s += x[r * N + c0 + c];
+    if (p < P) {
+        int64_t r = r0 + p;
+        for (; r + 3 * P < r1; r += 4 * P) {                        // four loads in flight, added in row order
+            const float v0 = x[r * N + c0 + c], v1 = x[(r + P) * N + c0 + c], v2 = x[(r + 2 * P) * N + c0 + c], v3 = x[(r + 3 * P) * N + c0 + c];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; r < r1; r += P) s += x[r * N + c0 + c];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (p == 0) {
@@ -88,13 +94,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* x, int
     }
 }
 
-// out[i] (+)= sum over chunks of partial[chunk * stride + i], chunks in ascending order
+// out[i] (+)= sum over chunks of partial[chunk * stride + i].  A workgroup owns 16 consecutive outputs; 16 groups of threads
+// each add every 16th chunk (ascending), and the group sums are added in group order: a fixed order for a given shape.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* partial, int n_chunks, int64_t stride, int64_t n, float* out, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[16][17];
+    const int il = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + il;
     float s = 0.f;
-    for (int ch = 0; ch < n_chunks; ++ch) s += partial[(int64_t)ch * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < n)
+        for (int ch = cg; ch < n_chunks; ch += 16) s += partial[(int64_t)ch * stride + i];
+    red[cg][il] = s;
+    __syncthreads();
+    if (cg == 0 && i < n) {
+        float t = red[0][il];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += red[g][il];
+        out[i] = accumulate ? out[i] + t : t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ dW = dY^T X, db = colsum(dY)
@@ -120,8 +136,8 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* dy, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bsum = 0.f;
-    for (int64_t base = w0; base < w1; base += 8) {
-        float a[4], b[4];
+    float a[4], b[4];
+    auto fetch = [&](int64_t base) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t rr = base + 2 * j + half;
@@ -129,10 +145,17 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* dy, con
             a[j] = (ok && n_ok) ? dy[rr * N + n] : 0.f;
             b[j] = (ok && k_ok) ? x[rr * K + k] : 0.f;
         }
+    };
+    fetch(w0);
+    for (int64_t base = w0; base < w1; base += 8) {
+        float ca[4], cb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ca[j] = a[j]; cb[j] = b[j]; }
+        fetch(base + 8);                                            // the next eight rows are in flight under these products
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[j], 0, 0, 0);
-            bsum += a[j];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[j], cb[j], acc[j], 0, 0, 0);
+            bsum += ca[j];
         }
     }
 #pragma unroll
@@ -219,6 +242,8 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
     const int last = mask_off < 0 ? Skv - 1 : min(Skv - 1, ic + mask_off);       // last visible key of this query
     const float* kb = k + (int64_t)b * Skv * ld + h * DH;
     const float* vb = v + (int64_t)b * Skv * ld + h * DH;
+    // pass 1: the largest score only (no exponential); pass 2 accumulates with weights 2^(s - m) and divides by their sum at
+    // the end: dq = scale / l * sum_j 2^(s_j - m) (dout . v_j - D) k_j,  log-sum-exp = m + log2 l
     float m = -INFINITY, l = 0.f;
     for (int j0 = 0; j0 < Skv; j0 += 128) {
         __syncthreads();
@@ -232,12 +257,9 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < DH; ++e) s = fmaf(qs[e], ks[jj][e], s);
-            const float mn = fmaxf(m, s);
-            l = l * exp2f(m - mn) + exp2f(s - mn);
-            m = mn;
+            m = fmaxf(m, s);
         }
     }
-    const float lse = m + log2f(l);
     for (int j0 = 0; j0 < Skv; j0 += 128) {
         __syncthreads();
         for (int idx = threadIdx.x; idx < 128 * DH; idx += 128) {
@@ -252,11 +274,15 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
             float s = 0.f, dp = 0.f;
 #pragma unroll
             for (int e = 0; e < DH; ++e) { s = fmaf(qs[e], ks[jj][e], s); dp = fmaf(go[e], vs[jj][e], dp); }
-            const float ds = exp2f(s - lse) * (dp - D);
+            const float p = exp2f(s - m);
+            l += p;
+            const float ds = p * (dp - D);
 #pragma unroll
             for (int e = 0; e < DH; ++e) dqa[e] = fmaf(ds, ks[jj][e], dqa[e]);
         }
     }
+    const float lse = m + log2f(l);
+    scale /= l;
     if (!valid) return;
 #pragma unroll
     for (int e = 0; e < DH; ++e) dq[qoff + e] = dqa[e] * scale;
@@ -313,12 +339,13 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
 }
 
 unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+unsigned reduce_blocks(int64_t n) { return (unsigned)((n + 15) / 16); }
 
 // rows per chunk (a multiple of 32) and number of chunks for a reduction over M rows
 void chunking(int64_t M, int64_t* rows_per_chunk, int* n_chunks) {
-    int64_t rpc = (M + 511) / 512;
+    int64_t rpc = (M + 511) / 512;                                  // at most 512 chunks; short chunks keep small problems parallel
     rpc = ((rpc + 31) / 32) * 32;
-    if (rpc < 256) rpc = 256;
+    if (rpc < 32) rpc = 32;
     *rows_per_chunk = rpc;
     *n_chunks = (int)((M + rpc - 1) / rpc);
 }
@@ -375,7 +402,7 @@ ADX_API int adx_op_colsum(const float* x, int64_t M, int N, float* out, int accu
     chunking(M, &rpc, &nc);
     float* partial = static_cast<float*>(workspace);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nc), dim3(256), 0, (hipStream_t)stream, x, M, N, rpc, partial);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, (hipStream_t)stream, partial, nc, (int64_t)N, (int64_t)N, out,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_blocks(N)), dim3(256), 0, (hipStream_t)stream, partial, nc, (int64_t)N, (int64_t)N, out,
                        accumulate);
     return done(hipGetLastError(), "colsum");
 }
@@ -391,10 +418,10 @@ ADX_API int adx_op_linear_wgrad(const float* dy, const float* x, int64_t M, int 
     const int64_t stride = (int64_t)N * K + N;
     const int tiles = ((N + 31) / 32) * ((K + 31) / 32);
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(tiles, nc), dim3(256), 0, (hipStream_t)stream, dy, x, M, N, K, rpc, partial, stride, db ? 1 : 0);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for((int64_t)N * K)), dim3(256), 0, (hipStream_t)stream, partial, nc, stride,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_blocks((int64_t)N * K)), dim3(256), 0, (hipStream_t)stream, partial, nc, stride,
                        (int64_t)N * K, dw, accumulate);
     if (db)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks_for(N)), dim3(256), 0, (hipStream_t)stream, partial + (int64_t)N * K, nc, stride,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(reduce_blocks(N)), dim3(256), 0, (hipStream_t)stream, partial + (int64_t)N * K, nc, stride,
                            (int64_t)N, db, accumulate);
     return done(hipGetLastError(), "linear_wgrad");
 }

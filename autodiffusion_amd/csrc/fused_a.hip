@@ -165,6 +165,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // No clamp is needed past the fitted range: the polynomial keeps falling (its leading coefficient is negative), 2^q underflows
 // to zero and the term stays below 6e-8 for every t >= 5.6.  (Writing the last step as plain FMAs with |v| and the negation
 // as operand modifiers measured slower: the compiler materialises -|v| and canonicalises the maximum, 25 us instead of 18.)
+// max(v, 0) as exactly one instruction (the median of v, 0 and 3e38; with +inf the compiler folds it back into the two-instruction maximum): the builtin maximum first canonicalises its operand with
+// a second v_max_f32 (quieting of signalling NaNs), one more vector instruction per element of the hidden layer.  Not inline
+// assembly: the compiler does not insert the wait states between a matrix instruction's write and a vector read of the same
+// register for an instruction it cannot see.
+__device__ __forceinline__ float max0(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.0e38f); }
+
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per call: the polynomial runs on packed fp32 FMAs
     const f32x2 t = __builtin_elementwise_abs(v);
     f32x2 q = t * -4.72791765e-04f + 7.08039424e-03f;
@@ -173,7 +179,7 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per cal
     q = t * q + -1.15078008e+00f;
     q = t * q + -1.00003892e+00f;
     const f32x2 e = {exp2_fast(q.x), exp2_fast(q.y)};
-    return __builtin_elementwise_max(v, f32x2{0.f, 0.f}) - t * e;
+    return f32x2{max0(v.x), max0(v.y)} - t * e;
 }
 
 // the same function on one value with plain (unpacked) FMAs: measurement aid for the packed form

@@ -272,7 +272,7 @@ class DiffusionWrapper(nn.Module):
         with torch.no_grad():
             return self._p_losses_value(prior, x_start, t, noise, return_rows)
 
-    def _p_losses_grad(self, prior, x_start, t, noise, return_rows):
+    def _p_losses_grad(self, prior, x_start, t, noise, return_rows, maps_repeat: int = 1):
         from . import ops, train
         x0 = _lib.f32c(x_start)
         tran, pri = prior["transition_info"], _lib.f32c(prior["trajectory_prior"])
@@ -292,7 +292,7 @@ class DiffusionWrapper(nn.Module):
         noise = _lib.f32c(noise if noise is not None else torch.randn_like(x0))
         x, v = ops.q_sample(x0, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, want_v=self.objective == "pred_v")
         cond = dict(maps_info=prior.get("maps_info"), transition_info=tran, trajectory_prior=pri)
-        model_out = train.denoise_with_grad(self.model, x, t, cond, self.model._n_head)
+        model_out = train.denoise_with_grad(self.model, x, t, cond, self.model._n_head, maps_repeat)
         target = {"pred_noise": noise, "pred_x0": x0, "pred_v": v}[self.objective]
         mean = train.WeightedMSE.apply(model_out, target, t, self.loss_weight)
         if return_rows:
@@ -428,6 +428,22 @@ class DiffusionAugmentation(nn.Module):
         n_chunks = S // fs
         label = _lib.f32c(trajectory_label).reshape(B, n_chunks, fs, -1)
         prior = _lib.f32c(trajectory_prior).reshape(B, n_chunks, fs, -1)
+        from . import train
+        if train.wants_grad(self.diffusion.diffusion.model):
+            # Training: the chunks do not depend on each other here (every chunk after the first sees a zero transition), so
+            # they run as ONE batch of n_chunks * B rows (row = chunk * B + scenario) that shares the scenarios' map tokens.
+            C = label.shape[-1]
+            rows = lambda v: v.permute(1, 0, 2, 3).reshape(n_chunks * B, fs, C).contiguous()  # noqa: E731
+            transition = torch.cat([self.init_x[None].expand(B, fs, C).to(torch.float32),
+                                    torch.zeros((n_chunks - 1) * B, fs, C, device=label.device, dtype=torch.float32)], dim=0)
+            cond = {"maps_info": maps_info, "transition_info": transition, "trajectory_prior": rows(prior)}
+            mean, per_row = self.diffusion.diffusion._p_losses_grad(
+                cond, rows(label), None if t is None else t.reshape(-1), None if noise is None else noise.reshape(n_chunks * B, fs, C),
+                True, maps_repeat=n_chunks)
+            rescale = float(getattr(self.diffusion.cfg, "trajectory_loss_rescale", 1.0))
+            final_predict = torch.zeros(B, S, C, device=label.device, dtype=torch.float32)
+            return LTMOutput(loss=mean * rescale, loss_items=per_row.reshape(n_chunks, B).mean(dim=1) * rescale, logits=final_predict,
+                             pred_dict={"traj_logits": final_predict}, trajectory_label=trajectory_label)
         transition = self.init_x[None].expand(B, *self.init_x.shape).contiguous()
         was_training = self.diffusion.training
         self.diffusion.train()                # the wrapper's forward() switches on the mode: loss when training, sample otherwise

@@ -129,10 +129,16 @@ class _Grads:
     def __init__(self, params: Dict[str, torch.Tensor]):
         self.params = params
         self.g: Dict[str, torch.Tensor] = {}
+        total = sum(p.numel() for p in params.values())
+        first = next(iter(params.values()))
+        self.flat = torch.zeros(total, device=first.device, dtype=torch.float32)     # one fill for every gradient
+        self.at = 0
 
     def of(self, name: str) -> torch.Tensor:
         if name not in self.g:
-            self.g[name] = torch.zeros_like(self.params[name], dtype=torch.float32, memory_format=torch.contiguous_format)
+            p = self.params[name]
+            self.g[name] = self.flat[self.at:self.at + p.numel()].view(p.shape)
+            self.at += p.numel()
         return self.g[name]
 
 
@@ -198,14 +204,19 @@ def _norm(P, prefix: str, x):
     return ops.layernorm(x, P[prefix + "weight"], P[prefix + "bias"], eps=1e-5)
 
 
-def denoiser_forward(P: Dict[str, torch.Tensor], x, t, maps, transition, prior, n_head: int, n_enc: int, n_dec: int):
-    """transformer.py:189-273 with every intermediate a backward needs kept.  -> (out (B, T, C), tape)."""
+def denoiser_forward(P: Dict[str, torch.Tensor], x, t, maps, transition, prior, n_head: int, n_enc: int, n_dec: int, maps_repeat: int = 1):
+    """transformer.py:189-273 with every intermediate a backward needs kept.  -> (out (B, T, C), tape).
+    ``maps_repeat`` = r: ``maps`` holds B / r scenarios and batch row i uses scenario i % (B / r) -- the chunks of one trajectory
+    share their map tokens, so the map embedding (the widest product of the network) is computed once and tiled."""
     d = P["input_emb.weight"].shape[0]
     B, T = x.shape[0], x.shape[1]
-    tape: Dict[str, object] = {"x": x, "maps": maps, "transition": transition, "prior": prior}
+    tape: Dict[str, object] = {"x": x, "maps": maps, "transition": transition, "prior": prior, "maps_repeat": maps_repeat}
     parts = [ops.timestep_embedding(t, d)[:, None, :]]
     if maps is not None:
-        parts.append(_lin(P, maps, "cond_obs_emb."))
+        if maps.shape[0] * maps_repeat != B:
+            raise ValueError("maps_info must hold batch / maps_repeat scenarios")
+        me = _lin(P, maps, "cond_obs_emb.")
+        parts.append(me if maps_repeat == 1 else me.repeat(maps_repeat, 1, 1))
     parts += [_lin(P, transition, "prior_z_emb."), _lin(P, prior, "prior_z_emb.")]
     c = torch.cat(parts, dim=1)
     S = c.shape[1]
@@ -271,8 +282,13 @@ def denoiser_backward(P: Dict[str, torch.Tensor], tape, dout, n_head: int, want_
     colsum(dc, _slice_rows(G.of("cond_pos_emb"), S))
     at = 1
     if maps is not None:
-        n_maps = maps.shape[1]
-        _lin_bwd(P, G, dc[:, at:at + n_maps].contiguous(), maps, "cond_obs_emb.", need_dx=False)
+        n_maps, rep = maps.shape[1], tape["maps_repeat"]
+        dme = dc[:, at:at + n_maps].contiguous()
+        if rep > 1:                                                 # the tiled embedding's gradient: sum over the repeats
+            folded = torch.zeros(maps.shape[0], n_maps, d, device=dme.device, dtype=torch.float32)
+            colsum(dme, folded.reshape(-1))
+            dme = folded
+        _lin_bwd(P, G, dme, maps, "cond_obs_emb.", need_dx=False)
         at += n_maps
     n_tr = transition.shape[1]
     d_tr = _lin_bwd(P, G, dc[:, at:at + n_tr].contiguous(), transition, "prior_z_emb.", need_dx=want_transition_grad)
@@ -292,16 +308,17 @@ class DenoiserA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, x, t, maps, transition, prior, *params):
-        names, n_head, n_enc, n_dec = meta
+        names, n_head, n_enc, n_dec, maps_repeat = meta
         P = {n: p.detach() for n, p in zip(names, params)}
-        out, tape = denoiser_forward(P, f32c(x), t, f32c(maps) if maps is not None else None, f32c(transition), f32c(prior), n_head, n_enc, n_dec)
+        out, tape = denoiser_forward(P, f32c(x), t, f32c(maps) if maps is not None else None, f32c(transition), f32c(prior), n_head, n_enc, n_dec,
+                                     maps_repeat)
         ctx.meta, ctx.P, ctx.tape = meta, P, tape
         ctx.want_tr = bool(ctx.needs_input_grad[4])
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        names, n_head, _, _ = ctx.meta
+        names, n_head = ctx.meta[0], ctx.meta[1]
         grads, d_tr = denoiser_backward(ctx.P, ctx.tape, dout.contiguous(), n_head, ctx.want_tr)
         ctx.tape = None
         return (None, None, None, None, d_tr, None) + tuple(grads.get(n) for n in names)
@@ -326,13 +343,13 @@ def trainable_names(module: torch.nn.Module) -> List[str]:
     return [n for n, _ in module.named_parameters()]
 
 
-def denoise_with_grad(module: torch.nn.Module, x, t, condition: Dict[str, torch.Tensor], n_head: int) -> torch.Tensor:
+def denoise_with_grad(module: torch.nn.Module, x, t, condition: Dict[str, torch.Tensor], n_head: int, maps_repeat: int = 1) -> torch.Tensor:
     """Differentiable call of a ``refiner.Transformer``: the result carries a grad_fn whose backward fills the module's ``.grad``s."""
     names = trainable_names(module)
     params = [p for _, p in module.named_parameters()]
     n_enc, n_dec = len(module.encoder.layers), len(module.decoder.layers)
     maps = condition.get("maps_info") if module.map_cond else None
-    return DenoiserA.apply((tuple(names), n_head, n_enc, n_dec), x, t, maps, condition["transition_info"], condition["trajectory_prior"], *params)
+    return DenoiserA.apply((tuple(names), n_head, n_enc, n_dec, int(maps_repeat)), x, t, maps, condition["transition_info"], condition["trajectory_prior"], *params)
 
 
 def wants_grad(module: torch.nn.Module) -> bool:
