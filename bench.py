@@ -19,7 +19,8 @@ touches a GPU) and relays rank 0's line.
 Rank 0 prints one JSON line.  ``roofline`` describes the kernel that dominates the step (measured live with events on the
 launch stream); ``cpu_baseline`` times the CPU oracle on a bounded sample of BASELINE.json configs[0]; ``knee`` is the same
 workload at 4096 scenarios per GPU (where every kernel fills the chip); ``dit_gemm`` is the dominant GEMM of the scaled DiT
-decoder (M = 256 x 80 tokens, N = 4096, K = 1024) timed live, the second half of the metric.
+decoder (M = 256 x 80 tokens, N = 4096, K = 1024) timed live, the second half of the metric; ``train_step`` is one optimisation
+step of the same refiner on the library's training path (forward + backward + update) at the reference's training batch.
 """
 from __future__ import annotations
 
@@ -278,6 +279,40 @@ def dit_gemm(dev):
     return out
 
 
+def train_step(dev, B=64, steps=5):
+    """One optimisation step of the refiner on the HIP training path at the reference's training batch (script/trainingRefiner.sh:
+    per_device_train_batch_size 64): DiffusionAugmentation.forward in gradient mode (the 8 chunks as one batch: q_sample, the
+    denoiser with kept activations, min-SNR weighted loss), loss.backward() through the library's backward kernels, SGD update.
+    fp32.  Reported beside the sampling metric; it is not part of ``value``."""
+    from autodiffusion_amd import refiner, synth
+    cfg = refiner.refiner_config(frame_stack=FS, diffusion_timesteps=N_TRAIN, objective="pred_noise", beta_schedule="cosine")
+    da = refiner.DiffusionAugmentation(cfg)
+    synth.reference_init_(da, 11)
+    da = da.to(dev).train()
+    maps, prior = synth.maps_info(B, 7).to(dev), synth.trajectory_prior(B, 7).to(dev)
+    label = prior + synth.noise(B, (), (80, 4), 1235).to(dev) * torch.tensor([1.5, 0.4, 0.0, 0.05], device=dev)
+    opt = torch.optim.SGD(da.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = da(trajectory_prior=prior, maps_info=maps, trajectory_label=label).loss
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    if not bool(torch.isfinite(loss.detach())):
+        raise RuntimeError("training step produced a non-finite loss")
+    return {"workload": f"refiner training step (forward + backward + SGD), frame_stack {FS} x {80 // FS} chunks, B={B}, fp32",
+            "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1), "steps": steps}
+
+
 def launch_ranks(args):
     """--gpus N without a launcher: start the N ranks as a fresh child (never from a process that initialised a GPU) and
     relay its output; rank 0 of the child prints the JSON line."""
@@ -431,6 +466,7 @@ def main():
         knee["roofline_frac"], knee["launch_us"] = r2["frac"], r2["launch_us"]
         line["knee"] = knee
         line["dit_gemm"] = dit_gemm(dev)
+        line["train_step"] = train_step(dev)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
