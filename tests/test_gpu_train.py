@@ -199,3 +199,41 @@ def test_init_x_gradient_and_a_training_step(dev):
         opt.step()
         first = float(loss) if first is None else first
     assert float(loss) < first
+
+
+def test_distributed_data_parallel_wraps_the_training_path(dev):
+    """torch's DistributedDataParallel over RCCL (a process group of this one rank) around the accelerated module: its gradient
+    hooks fire on the gradients the library's backward returns, and the averaged gradients equal the unwrapped module's."""
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from autodiffusion_amd import refiner, synth
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    fs, N, B = 10, 100, 4
+    maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED).to(dev)
+    label = prior + synth.noise(B, (), (80, 4), NSEED + 1).to(dev) * torch.tensor([1.5, 0.4, 0.0, 0.05], device=dev)
+    t = torch.from_numpy(np.random.default_rng(5).integers(0, N, size=(8, B)).astype(np.int64)).to(dev)
+    noise = synth.noise(B, (8,), (fs, 4), NSEED + 2).to(dev)
+
+    def build():
+        da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N))
+        synth.fill_module_(da.diffusion, WSEED)
+        return da.to(dev).train()
+    plain = build()
+    plain(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=t, noise=noise).loss.backward()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        wrapped = build()
+        wrapped.init_x.data.copy_(plain.init_x.data)
+        ddp = DistributedDataParallel(wrapped, device_ids=[dev.index])
+        ddp(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=t, noise=noise).loss.backward()
+        torch.cuda.synchronize()
+        for (n, a), (_, b) in zip(plain.named_parameters(), wrapped.named_parameters()):
+            assert a.grad is not None and b.grad is not None, n
+            assert torch.equal(a.grad, b.grad), n
+    finally:
+        dist.destroy_process_group()
