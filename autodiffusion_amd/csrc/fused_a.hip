@@ -190,7 +190,7 @@ __device__ __forceinline__ float gelu_erf1(float v) {
     q = fmaf(t, q, -4.60007281e-01f);
     q = fmaf(t, q, -1.15078008e+00f);
     q = fmaf(t, q, -1.00003892e+00f);
-    return fmaf(-av, exp2_fast(q), fmaxf(v, 0.f));
+    return fmaf(-av, exp2_fast(q), max0(v));
 }
 
 __device__ __forceinline__ f32x16 zero16() {

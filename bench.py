@@ -75,7 +75,7 @@ def time_kernel(fn, iters=20):
 # HBM bytes of one launch of the encoder row kernel at B = 1024 from the L2 fabric-request counters (separate rocprofv3
 # --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
 # the per-row figure scales with B.  Source: profiles/r02_pmc_refiner.txt.
-ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (1870561.6 * 128 + 1701910.1 * 64) / (1024 * L_COND)
+ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (1874131.7 * 128 + 1701898.4 * 64) / (1024 * L_COND)
 def enc_rows_read_bytes_per_row(B, n_steps):
     """x0 (128) + the cached attention output o / l (128) + this step's gates (32) while the per-chunk gate table fits the
     engine's budget (its rule, ADX_GATE_TABLE_MAX_MB included); otherwise x0 + layer-0 query (128) + normalised state (160)."""
