@@ -31,7 +31,7 @@ EXPORTS = [
     "adx_engine_set_noise_seed", "adx_op_randn", "adx_engine_capture_count", "adx_op_q_sample", "adx_op_weighted_mse",
     "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes",
     "adx_op_add", "adx_op_transpose", "adx_op_gelu", "adx_op_gelu_bwd", "adx_reduce_ws_bytes", "adx_op_linear_wgrad", "adx_op_colsum",
-    "adx_op_layernorm_bwd", "adx_op_attention_bwd", "adx_op_weighted_mse_bwd",
+    "adx_op_layernorm_bwd", "adx_op_attention_bwd", "adx_op_attention_stats", "adx_op_weighted_mse_bwd",
 ]
 
 
@@ -114,7 +114,8 @@ def load() -> C.CDLL:
         "adx_op_linear_wgrad": ([p, p, i64, i, i, p, p, i, p, C.c_size_t, p], i),
         "adx_op_colsum": ([p, i64, i, p, i, p, C.c_size_t, p], i),
         "adx_op_layernorm_bwd": ([p, p, p, i64, i, f, p, p, p], i),
-        "adx_op_attention_bwd": ([p, p, p, p, p, i, i, i, i, i, f, i, p, p, p, p, p], i),
+        "adx_op_attention_bwd": ([p, p, p, p, p, i, i, i, i, i, f, i, p, p, p, p, i, p], i),
+        "adx_op_attention_stats": ([p, p, p, p, p, i, i, i, i, i, f, i, p], i),
         "adx_op_weighted_mse_bwd": ([p, p, p, p, p, p, i, i, p], i),
     }
     for name, (args, res) in protos.items():

@@ -25,6 +25,10 @@ int done(hipError_t e, const char* what) { return e == hipSuccess ? ADX_OK : hip
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+// 2^x as the single hardware instruction: the arguments here are differences to a running or final maximum (<= 0 up to
+// rounding), so the library function's range handling (compare, two selects, ldexp per call) buys nothing
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // ------------------------------------------------------------------------------------------------ elementwise
 __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -218,46 +222,67 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
 
 // ------------------------------------------------------------------------------------------------ attention backward
 // q[B][Sq][H*DH], k / v[B][Skv][H*DH], o / dout[B][Sq][H*DH]; key j is visible to query i iff mask_off < 0 or j <= i + mask_off.
-// Pass over queries: thread = query; the log-sum-exp of its scores (base 2) and D = dout . o are kept for the key pass;
+// Head widths this small fit no matrix-core shape (the f32 matrix rate equals the vector rate on this part, and bf16 products
+// on split operands would waste 7/8 of a tile on the zeros of a block-diagonal head layout), so both passes are vector code.
+// What bounds them is the LDS broadcast of the other side's rows (one LDS pipe serves the four SIMDs of a CU), so a thread
+// owns PT queries (keys) 128 apart and every row read from LDS is used PT times.
+//
+// Pass over queries: the log-sum-exp of a query's scores (base 2) and D = dout . o are kept for the key pass;
 //   dq_i = scale * sum_j dS_ij k_j,   dS_ij = P_ij (dout_i . v_j - D_i).
-template <int DH>
+// First the largest score only (no exponential), then one exponential per pair with weights 2^(s - m), divided by their sum
+// at the end:  dq = scale / l * sum_j 2^(s_j - m) (dout . v_j - D) k_j,  log-sum-exp = m + log2 l.
+// HAVE_LSE: stats already holds the log-sum-exp of every query (written by attn_fwd_stats_kernel): the maximum pass is skipped
+// and the weights are the probabilities themselves.
+template <int DH, int PT, bool MASKED, bool HAVE_LSE>
 __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
                                                               int H, int Sq, int Skv, float scale, int mask_off, float* dq, float* stats) {
     __shared__ float ks[128][DH], vs[128][DH];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int i = blockIdx.x * 128 + threadIdx.x;
-    const bool valid = i < Sq;
     const int ld = H * DH;
-    const int ic = valid ? i : Sq - 1;
-    const int64_t qoff = ((int64_t)b * Sq + ic) * ld + h * DH;
-    float qs[DH], go[DH], dqa[DH];
-    float D = 0.f;
+    int iq[PT], last[PT];
+    bool valid[PT];
+    int64_t qoff[PT];
+    float qs[PT][DH], go[PT][DH], dqa[PT][DH], D[PT], m[PT], l[PT];
+    int last_all = 0;
 #pragma unroll
-    for (int e = 0; e < DH; ++e) {
-        qs[e] = q[qoff + e] * (scale * kLog2e);
-        go[e] = dout[qoff + e];
-        D = fmaf(go[e], o[qoff + e], D);
-        dqa[e] = 0.f;
+    for (int u = 0; u < PT; ++u) {
+        iq[u] = blockIdx.x * (128 * PT) + 128 * u + threadIdx.x;
+        valid[u] = iq[u] < Sq;
+        const int ic = valid[u] ? iq[u] : Sq - 1;
+        qoff[u] = ((int64_t)b * Sq + ic) * ld + h * DH;
+        D[u] = 0.f; m[u] = -INFINITY; l[u] = 0.f;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            qs[u][e] = q[qoff[u] + e] * (scale * kLog2e);
+            go[u][e] = dout[qoff[u] + e];
+            D[u] = fmaf(go[u][e], o[qoff[u] + e], D[u]);
+            dqa[u][e] = 0.f;
+        }
+        last[u] = MASKED ? min(Skv - 1, ic + mask_off) : Skv - 1;               // last visible key of this query
+        last_all = max(last_all, last[u]);
+        if (HAVE_LSE) { m[u] = stats[(((int64_t)b * H + h) * Sq + ic) * 2]; l[u] = 1.0f; }
     }
-    const int last = mask_off < 0 ? Skv - 1 : min(Skv - 1, ic + mask_off);       // last visible key of this query
     const float* kb = k + (int64_t)b * Skv * ld + h * DH;
     const float* vb = v + (int64_t)b * Skv * ld + h * DH;
-    // pass 1: the largest score only (no exponential); pass 2 accumulates with weights 2^(s - m) and divides by their sum at
-    // the end: dq = scale / l * sum_j 2^(s_j - m) (dout . v_j - D) k_j,  log-sum-exp = m + log2 l
-    float m = -INFINITY, l = 0.f;
-    for (int j0 = 0; j0 < Skv; j0 += 128) {
+    for (int j0 = 0; j0 < (HAVE_LSE ? 0 : Skv); j0 += 128) {
         __syncthreads();
         for (int idx = threadIdx.x; idx < 128 * DH; idx += 128) {
             const int jj = idx / DH, e = idx % DH;
             ks[jj][e] = j0 + jj < Skv ? kb[(int64_t)(j0 + jj) * ld + e] : 0.f;
         }
         __syncthreads();
-        const int jn = min(128, last - j0 + 1);
+        const int jn = min(128, last_all - j0 + 1);
         for (int jj = 0; jj < jn; ++jj) {
-            float s = 0.f;
+            float kr[DH];
 #pragma unroll
-            for (int e = 0; e < DH; ++e) s = fmaf(qs[e], ks[jj][e], s);
-            m = fmaxf(m, s);
+            for (int e = 0; e < DH; ++e) kr[e] = ks[jj][e];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < DH; ++e) s = fmaf(qs[u][e], kr[e], s);
+                if (!MASKED || j0 + jj <= last[u]) m[u] = fmaxf(m[u], s);
+            }
         }
     }
     for (int j0 = 0; j0 < Skv; j0 += 128) {
@@ -269,43 +294,155 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
             vs[jj][e] = ok ? vb[(int64_t)(j0 + jj) * ld + e] : 0.f;
         }
         __syncthreads();
-        const int jn = min(128, last - j0 + 1);
+        const int jn = min(128, last_all - j0 + 1);
         for (int jj = 0; jj < jn; ++jj) {
-            float s = 0.f, dp = 0.f;
+            float kr[DH], vr[DH];
 #pragma unroll
-            for (int e = 0; e < DH; ++e) { s = fmaf(qs[e], ks[jj][e], s); dp = fmaf(go[e], vs[jj][e], dp); }
-            const float p = exp2f(s - m);
-            l += p;
-            const float ds = p * (dp - D);
+            for (int e = 0; e < DH; ++e) { kr[e] = ks[jj][e]; vr[e] = vs[jj][e]; }
 #pragma unroll
-            for (int e = 0; e < DH; ++e) dqa[e] = fmaf(ds, ks[jj][e], dqa[e]);
+            for (int u = 0; u < PT; ++u) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int e = 0; e < DH; ++e) { s = fmaf(qs[u][e], kr[e], s); dp = fmaf(go[u][e], vr[e], dp); }
+                float p = exp2_raw(s - m[u]);
+                if (MASKED && j0 + jj > last[u]) p = 0.f;
+                if (!HAVE_LSE) l[u] += p;
+                const float ds = p * (dp - D[u]);
+#pragma unroll
+                for (int e = 0; e < DH; ++e) dqa[u][e] = fmaf(ds, kr[e], dqa[u][e]);
+            }
         }
     }
-    const float lse = m + log2f(l);
-    scale /= l;
-    if (!valid) return;
 #pragma unroll
-    for (int e = 0; e < DH; ++e) dq[qoff + e] = dqa[e] * scale;
-    float* st = stats + (((int64_t)b * H + h) * Sq + i) * 2;
-    st[0] = lse;
-    st[1] = D;
+    for (int u = 0; u < PT; ++u) {
+        if (!valid[u]) continue;
+        const float f = scale / l[u];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) dq[qoff[u] + e] = dqa[u][e] * f;
+        float* st = stats + (((int64_t)b * H + h) * Sq + iq[u]) * 2;
+        if (!HAVE_LSE) st[0] = m[u] + log2f(l[u]);
+        st[1] = D[u];
+    }
 }
 
-// Pass over keys: thread = key;  dv_j = sum_i P_ij dout_i,   dk_j = scale * sum_i dS_ij q_i.
-template <int DH>
+// Forward attention of the training path: o, and per (query, head) the log-sum-exp of the scores (base 2) in stats[..][0], so
+// that the backward needs no pass of its own to find it.  Thread = PT queries, online softmax over blocks of 8 keys.
+template <int DH, int PT, bool MASKED>
+__global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, const float* k, const float* v, int H, int Sq, int Skv, float scale,
+                                                              int mask_off, float* o, float* stats) {
+    __shared__ float ks[128][DH], vs[128][DH];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int ld = H * DH;
+    int iq[PT], last[PT];
+    bool valid[PT];
+    int64_t qoff[PT];
+    float qs[PT][DH], acc[PT][DH], m[PT], l[PT];
+    int last_all = 0;
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        iq[u] = blockIdx.x * (128 * PT) + 128 * u + threadIdx.x;
+        valid[u] = iq[u] < Sq;
+        const int ic = valid[u] ? iq[u] : Sq - 1;
+        qoff[u] = ((int64_t)b * Sq + ic) * ld + h * DH;
+        m[u] = -INFINITY; l[u] = 0.f;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) { qs[u][e] = q[qoff[u] + e] * (scale * kLog2e); acc[u][e] = 0.f; }
+        last[u] = MASKED ? min(Skv - 1, ic + mask_off) : Skv - 1;
+        last_all = max(last_all, last[u]);
+    }
+    const float* kb = k + (int64_t)b * Skv * ld + h * DH;
+    const float* vb = v + (int64_t)b * Skv * ld + h * DH;
+    for (int j0 = 0; j0 < Skv; j0 += 128) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 128 * DH; idx += 128) {
+            const int jj = idx / DH, e = idx % DH;
+            const bool ok = j0 + jj < Skv;
+            ks[jj][e] = ok ? kb[(int64_t)(j0 + jj) * ld + e] : 0.f;
+            vs[jj][e] = ok ? vb[(int64_t)(j0 + jj) * ld + e] : 0.f;
+        }
+        __syncthreads();
+        const int jn = min(128, last_all - j0 + 1);
+        for (int jb = 0; jb < jn; jb += 8) {
+            float sc[PT][8], mx[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) mx[u] = m[u];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int jj = min(jb + w, 127);
+                float kr[DH];
+#pragma unroll
+                for (int e = 0; e < DH; ++e) kr[e] = ks[jj][e];
+#pragma unroll
+                for (int u = 0; u < PT; ++u) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DH; ++e) d = fmaf(qs[u][e], kr[e], d);
+                    if (jb + w >= jn || (MASKED && j0 + jb + w > last[u])) d = -INFINITY;
+                    sc[u][w] = d;
+                    mx[u] = fmaxf(mx[u], d);
+                }
+            }
+            float alpha[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                alpha[u] = mx[u] == -INFINITY ? 1.0f : exp2_raw(m[u] - mx[u]);      // nothing visible yet: keep the empty state
+                if (mx[u] == -INFINITY) mx[u] = 0.f;                                // (every score of the block is -inf: all weights 0)
+                l[u] *= alpha[u];
+#pragma unroll
+                for (int e = 0; e < DH; ++e) acc[u][e] *= alpha[u];
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const int jj = min(jb + w, 127);
+                float vr[DH];
+#pragma unroll
+                for (int e = 0; e < DH; ++e) vr[e] = vs[jj][e];
+#pragma unroll
+                for (int u = 0; u < PT; ++u) {
+                    const float p = exp2_raw(sc[u][w] - mx[u]);
+                    l[u] += p;
+#pragma unroll
+                    for (int e = 0; e < DH; ++e) acc[u][e] = fmaf(p, vr[e], acc[u][e]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PT; ++u)
+                if (l[u] > 0.f) m[u] = mx[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PT; ++u) {
+        if (!valid[u]) continue;
+        const float inv = 1.0f / l[u];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) o[qoff[u] + e] = acc[u][e] * inv;
+        stats[(((int64_t)b * H + h) * Sq + iq[u]) * 2] = m[u] + log2f(l[u]);
+    }
+}
+
+// Pass over keys: thread = PT keys;  dv_j = sum_i P_ij dout_i,   dk_j = scale * sum_i dS_ij q_i.
+template <int DH, int PT, bool MASKED>
 __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const float* k, const float* v, const float* dout, const float* stats,
                                                             int H, int Sq, int Skv, float scale, int mask_off, float* dk, float* dv) {
     __shared__ float qsh[128][DH], gsh[128][DH], ssh[128][2];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int j = blockIdx.x * 128 + threadIdx.x;
-    const bool valid = j < Skv;
     const int ld = H * DH;
-    const int jc = valid ? j : Skv - 1;
-    const int64_t koff = ((int64_t)b * Skv + jc) * ld + h * DH;
-    float kk[DH], vv[DH], dka[DH], dva[DH];
+    int jk[PT], first[PT];
+    bool valid[PT];
+    int64_t koff[PT];
+    float kk[PT][DH], vv[PT][DH], dka[PT][DH], dva[PT][DH];
+    int first_all = Sq;
 #pragma unroll
-    for (int e = 0; e < DH; ++e) { kk[e] = k[koff + e]; vv[e] = v[koff + e]; dka[e] = 0.f; dva[e] = 0.f; }
-    const int first = mask_off < 0 ? 0 : max(0, jc - mask_off);                // first query that sees this key
+    for (int u = 0; u < PT; ++u) {
+        jk[u] = blockIdx.x * (128 * PT) + 128 * u + threadIdx.x;
+        valid[u] = jk[u] < Skv;
+        const int jc = valid[u] ? jk[u] : Skv - 1;
+        koff[u] = ((int64_t)b * Skv + jc) * ld + h * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) { kk[u][e] = k[koff[u] + e]; vv[u][e] = v[koff[u] + e]; dka[u][e] = 0.f; dva[u][e] = 0.f; }
+        first[u] = MASKED ? max(0, jc - mask_off) : 0;                          // first query that sees this key
+        first_all = min(first_all, first[u]);
+    }
     const float* qb = q + (int64_t)b * Sq * ld + h * DH;
     const float* gb = dout + (int64_t)b * Sq * ld + h * DH;
     const float* sb = stats + ((int64_t)b * H + h) * Sq * 2;
@@ -323,19 +460,30 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
         }
         __syncthreads();
         const int in = min(128, Sq - i0);
-        for (int ii = max(0, first - i0); ii < in; ++ii) {
-            float s = 0.f, dp = 0.f;
+        for (int ii = max(0, first_all - i0); ii < in; ++ii) {
+            float qr[DH], gr[DH];
 #pragma unroll
-            for (int e = 0; e < DH; ++e) { s = fmaf(qsh[ii][e], kk[e], s); dp = fmaf(gsh[ii][e], vv[e], dp); }
-            const float p = exp2f(s - ssh[ii][0]);
-            const float ds = p * (dp - ssh[ii][1]);
+            for (int e = 0; e < DH; ++e) { qr[e] = qsh[ii][e]; gr[e] = gsh[ii][e]; }
+            const float lse = ssh[ii][0], Di = ssh[ii][1];
 #pragma unroll
-            for (int e = 0; e < DH; ++e) { dva[e] = fmaf(p, gsh[ii][e], dva[e]); dka[e] = fmaf(ds, qsh[ii][e], dka[e]); }
+            for (int u = 0; u < PT; ++u) {
+                float s = 0.f, dp = 0.f;
+#pragma unroll
+                for (int e = 0; e < DH; ++e) { s = fmaf(qr[e], kk[u][e], s); dp = fmaf(gr[e], vv[u][e], dp); }
+                float p = exp2_raw(s - lse);
+                if (MASKED && i0 + ii < first[u]) p = 0.f;
+                const float ds = p * (dp - Di);
+#pragma unroll
+                for (int e = 0; e < DH; ++e) { dva[u][e] = fmaf(p, gr[e], dva[u][e]); dka[u][e] = fmaf(ds, qr[e], dka[u][e]); }
+            }
         }
     }
-    if (!valid) return;
 #pragma unroll
-    for (int e = 0; e < DH; ++e) { dk[koff + e] = dka[e] * (1.0f / kLog2e); dv[koff + e] = dva[e]; }
+    for (int u = 0; u < PT; ++u) {
+        if (!valid[u]) continue;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) { dk[koff[u] + e] = dka[u][e] * (1.0f / kLog2e); dv[koff[u] + e] = dva[u][e]; }
+    }
 }
 
 unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -440,16 +588,20 @@ ADX_API int adx_op_layernorm_bwd(const float* x, const float* gamma, const float
 }
 
 ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H, int Sq, int Skv,
-                                 int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, void* stream) {
+                                 int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, int stats_have_lse, void* stream) {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !stats) return fail(ADX_EINVAL, "attention_bwd: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_bwd: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_bwd: batch or head count above 65535");
-    const dim3 gq((Sq + 127) / 128, H, B), gk((Skv + 127) / 128, H, B);
+    constexpr int PT = 2;                                           // queries (keys) per thread
+    const dim3 gq((Sq + 128 * PT - 1) / (128 * PT), H, B), gk((Skv + 128 * PT - 1) / (128 * PT), H, B);
     hipStream_t s = (hipStream_t)stream;
-#define ADX_ATTN_BWD(DH)                                                                                                                   \
-    case DH:                                                                                                                               \
-        hipLaunchKernelGGL(attn_bwd_query_kernel<DH>, gq, dim3(128), 0, s, q, k, v, o, dout, H, Sq, Skv, scale, mask_off, dq, stats);      \
-        hipLaunchKernelGGL(attn_bwd_key_kernel<DH>, gk, dim3(128), 0, s, q, k, v, dout, stats, H, Sq, Skv, scale, mask_off, dk, dv);       \
+#define ADX_ATTN_BWD3(DH, MASKED, LSE)                                                                                                                  \
+    hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE>), gq, dim3(128), 0, s, q, k, v, o, dout, H, Sq, Skv, scale, mask_off, dq, stats);  \
+    hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED>), gk, dim3(128), 0, s, q, k, v, dout, stats, H, Sq, Skv, scale, mask_off, dk, dv);
+#define ADX_ATTN_BWD2(DH, MASKED) if (stats_have_lse) { ADX_ATTN_BWD3(DH, MASKED, true) } else { ADX_ATTN_BWD3(DH, MASKED, false) }
+#define ADX_ATTN_BWD(DH)                                              \
+    case DH:                                                          \
+        if (mask_off < 0) { ADX_ATTN_BWD2(DH, false) } else { ADX_ATTN_BWD2(DH, true) } \
         break;
     switch (dh) {
         ADX_ATTN_BWD(4)
@@ -458,5 +610,30 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
         default: return fail(ADX_EINVAL, "attention_bwd: head width must be 4, 8 or 16");
     }
 #undef ADX_ATTN_BWD
+#undef ADX_ATTN_BWD2
+#undef ADX_ATTN_BWD3
     return done(hipGetLastError(), "attention_bwd");
+}
+
+ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq, int Skv, int dh,
+                                   float scale, int mask_off, void* stream) {
+    if (!q || !k || !v || !o || !stats) return fail(ADX_EINVAL, "attention_stats: null pointer");
+    if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_stats: empty shape");
+    if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_stats: batch or head count above 65535");
+    constexpr int PT = 2;
+    const dim3 gq((Sq + 128 * PT - 1) / (128 * PT), H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define ADX_ATTN_FWD(DH)                                                                                                                         \
+    case DH:                                                                                                                                     \
+        if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false>), gq, dim3(128), 0, s, q, k, v, H, Sq, Skv, scale, mask_off, o, stats); \
+        else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true>), gq, dim3(128), 0, s, q, k, v, H, Sq, Skv, scale, mask_off, o, stats);     \
+        break;
+    switch (dh) {
+        ADX_ATTN_FWD(4)
+        ADX_ATTN_FWD(8)
+        ADX_ATTN_FWD(16)
+        default: return fail(ADX_EINVAL, "attention_stats: head width must be 4, 8 or 16");
+    }
+#undef ADX_ATTN_FWD
+    return done(hipGetLastError(), "attention_stats");
 }

@@ -94,8 +94,25 @@ def layernorm_bwd(x: torch.Tensor, gamma: Optional[torch.Tensor], dy: torch.Tens
     return dx, dyx
 
 
-def attention_bwd(q, k, v, o, dout, n_head: int, scale: Optional[float] = None, mask_off: int = -1):
-    """Backward of ``ops.attention`` (same layouts, same mask rule) -> (dq, dk, dv)."""
+def attention_stats(q, k, v, n_head: int, scale: Optional[float] = None, mask_off: int = -1):
+    """``ops.attention`` for a forward whose backward follows -> (o, stats); stats carries each query's log-sum-exp."""
+    q, k, v = f32c(q), f32c(k), f32c(v)
+    B, Sq, Skv = q.shape[0], q.shape[1], k.shape[1]
+    dh = q.shape[2] // n_head
+    if v.shape[2] != q.shape[2]:
+        raise ValueError("attention_stats: value width must equal the key width")
+    if scale is None:
+        scale = dh ** -0.5
+    o = torch.empty_like(q)
+    stats = torch.empty(B, n_head, Sq, 2, device=q.device, dtype=torch.float32)
+    check(_lib.load().adx_op_attention_stats(ptr(q), ptr(k), ptr(v), ptr(o), ptr(stats), B, n_head, Sq, Skv, dh, float(scale), int(mask_off),
+                                             current_stream()), "attention_stats")
+    return o, stats
+
+
+def attention_bwd(q, k, v, o, dout, n_head: int, scale: Optional[float] = None, mask_off: int = -1, stats: Optional[torch.Tensor] = None):
+    """Backward of ``ops.attention`` / ``attention_stats`` (same layouts, same mask rule) -> (dq, dk, dv).  ``stats`` from
+    ``attention_stats`` saves the pass that recomputes the log-sum-exps."""
     q, k, v, o, dout = f32c(q), f32c(k), f32c(v), f32c(o), f32c(dout)
     B, Sq, Skv = q.shape[0], q.shape[1], k.shape[1]
     dh = q.shape[2] // n_head
@@ -104,9 +121,12 @@ def attention_bwd(q, k, v, o, dout, n_head: int, scale: Optional[float] = None, 
     if scale is None:
         scale = dh ** -0.5
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    stats = torch.empty(B, n_head, Sq, 2, device=q.device, dtype=torch.float32)
+    have = stats is not None
+    if have and tuple(stats.shape) != (B, n_head, Sq, 2):
+        raise ValueError("attention_bwd: stats of the wrong shape")
+    st = stats if have else torch.empty(B, n_head, Sq, 2, device=q.device, dtype=torch.float32)
     check(_lib.load().adx_op_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), B, n_head, Sq, Skv, dh, float(scale), int(mask_off),
-                                           ptr(dq), ptr(dk), ptr(dv), ptr(stats), current_stream()), "attention_bwd")
+                                           ptr(dq), ptr(dk), ptr(dv), ptr(st), int(have), current_stream()), "attention_bwd")
     return dq, dk, dv
 
 
@@ -173,16 +193,16 @@ def _mha(P, prefix: str, xq, xkv, n_head: int, mask_off: int):
     q = _lin(P, xq, prefix + "in_proj_", slice(0, d))
     k = _lin(P, xkv, prefix + "in_proj_", slice(d, 2 * d))
     v = _lin(P, xkv, prefix + "in_proj_", slice(2 * d, 3 * d))
-    o = ops.attention(q, k, v, n_head, mask_off=mask_off)
-    return _lin(P, o, prefix + "out_proj."), (q, k, v, o)
+    o, stats = attention_stats(q, k, v, n_head, mask_off=mask_off)
+    return _lin(P, o, prefix + "out_proj."), (q, k, v, o, stats)
 
 
 def _mha_bwd(P, G, prefix: str, xq, xkv, saved, da, n_head: int, mask_off: int):
     """-> (d xq, d xkv) of ``out_proj(attention(q(xq), k(xkv), v(xkv)))``."""
-    q, k, v, o = saved
+    q, k, v, o, stats = saved
     d = xq.shape[-1]
     do = _lin_bwd(P, G, da, o, prefix + "out_proj.")
-    dq, dk, dv = attention_bwd(q, k, v, o, do, n_head, mask_off=mask_off)
+    dq, dk, dv = attention_bwd(q, k, v, o, do, n_head, mask_off=mask_off, stats=stats)
     dxq = _lin_bwd(P, G, dq, xq, prefix + "in_proj_", slice(0, d))
     dxkv = add(_lin_bwd(P, G, dk, xkv, prefix + "in_proj_", slice(d, 2 * d)), _lin_bwd(P, G, dv, xkv, prefix + "in_proj_", slice(2 * d, 3 * d)))
     return dxq, dxkv

@@ -119,6 +119,16 @@ def test_op_attention_bwd(dev, B, H, Sq, Skv, dh, mask_off):
     errs = [l2_rel(dq, qd.grad), l2_rel(dk, kd.grad), l2_rel(dv, vd.grad)]
     print("attention_bwd", (B, H, Sq, Skv, dh, mask_off), ["%.1e" % e for e in errs])
     assert max(errs) < 2e-5
+    # the training forward (output + log-sum-exps) and the backward that starts from its statistics
+    o2, stats = train.attention_stats(q.to(dev), k.to(dev), v.to(dev), H, mask_off=mask_off)
+    want_o = nets.attention(q.double(), k.double(), v.double(), H, allowed)
+    assert l2_rel(o2, want_o) < 2e-6 and l2_rel(o, want_o) < 2e-6
+    s = torch.einsum("bihd,bjhd->bhij", q.double().reshape(B, Sq, H, dh), k.double().reshape(B, Skv, H, dh)) * dh ** -0.5
+    if allowed is not None:
+        s = s.masked_fill(~allowed, float("-inf"))
+    assert float((stats[..., 0].cpu().double() - torch.logsumexp(s, -1) / np.log(2.0)).abs().max()) < 1e-4
+    dq2, dk2, dv2 = train.attention_bwd(q.to(dev), k.to(dev), v.to(dev), o2, do.to(dev), H, mask_off=mask_off, stats=stats)
+    assert max(l2_rel(dq2, qd.grad), l2_rel(dk2, kd.grad), l2_rel(dv2, vd.grad)) < 2e-5
 
 
 # ------------------------------------------------------------------ the whole backward
