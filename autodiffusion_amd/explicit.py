@@ -75,13 +75,22 @@ class TrajDiffusion(nn.Module):
                            _lib.FLAG_KEEP_MAPS if same_maps else 0)
         return out.squeeze(1)
 
-    @torch.no_grad()
     def forward(self, label, transition_info, trajectory_prior, maps_info, t: Optional[torch.Tensor] = None,
                 noise: Optional[torch.Tensor] = None):
-        """-> (loss (B, fs*4) element-wise squared error of the noise estimate, pred (B, fs*4)): traj_diffusion.py:83-124,
-        forward only.  The timestep is uniform in [1, num_train_timesteps) as there; ``add_noise`` is the public
-        ``sqrt(acp[t]) x + sqrt(1 - acp[t]) noise`` (third-party scheduler: parity unpinned)."""
-        from . import ops
+        """-> (loss (B, fs*4) element-wise squared error of the noise estimate, pred (B, fs*4)): traj_diffusion.py:83-124.
+        The timestep is uniform in [1, num_train_timesteps) as there; ``add_noise`` is the public
+        ``sqrt(acp[t]) x + sqrt(1 - acp[t]) noise`` (third-party scheduler: parity unpinned).  With gradients enabled and
+        trainable parameters the denoiser call is the differentiable training path (``train.py``), so the loss and ``pred`` --
+        which the wrapper feeds to the next chunk as its transition, un-detached as in the reference -- carry gradients;
+        under ``torch.no_grad()`` only the values are computed, on the sampling engine."""
+        from . import train
+        if train.wants_grad(self.diffusion):
+            return self._forward_impl(label, transition_info, trajectory_prior, maps_info, t, noise, True)
+        with torch.no_grad():
+            return self._forward_impl(label, transition_info, trajectory_prior, maps_info, t, noise, False)
+
+    def _forward_impl(self, label, transition_info, trajectory_prior, maps_info, t, noise, grad: bool):
+        from . import ops, train
         B = label.shape[0]
         W = self.cfg.trajectory_dim * self.cfg.frame_stack
         x0 = _lib.f32c(label).reshape(B, 1, W)
@@ -92,9 +101,14 @@ class TrajDiffusion(nn.Module):
         noise = torch.randn_like(x0) if noise is None else _lib.f32c(noise).reshape(B, 1, W)
         acp = torch.cumprod(1.0 - self.betas.to(torch.float32), dim=0)
         x, _ = ops.q_sample(x0, noise, t, acp.sqrt(), (1.0 - acp).sqrt())
-        cond = dict(maps_info=maps_info, transition_info=_lib.f32c(transition_info).reshape(B, 1, W),
-                    trajectory_prior=_lib.f32c(trajectory_prior).reshape(B, 1, W))
-        pred = self.diffusion(x, t, cond).reshape(B, W)
+        if grad:       # the transition keeps its autograd history (init_x, or the previous chunk's prediction)
+            cond = dict(maps_info=maps_info, transition_info=transition_info.to(torch.float32).reshape(B, 1, W),
+                        trajectory_prior=_lib.f32c(trajectory_prior).reshape(B, 1, W))
+            pred = train.denoise_with_grad(self.diffusion, x, t, cond, self.diffusion._n_head).reshape(B, W)
+        else:
+            cond = dict(maps_info=maps_info, transition_info=_lib.f32c(transition_info).reshape(B, 1, W),
+                        trajectory_prior=_lib.f32c(trajectory_prior).reshape(B, 1, W))
+            pred = self.diffusion(x, t, cond).reshape(B, W)
         return (pred - noise.reshape(B, W)) ** 2, pred
 
 
@@ -158,11 +172,18 @@ class ExplicitDiT(nn.Module):
         out = torch.stack(preds, dim=1).reshape(B, S, C)
         return {"traj_logits": self._unnormalize_x(out).to(torch.float32)}
 
-    @torch.no_grad()
     def forward(self, return_dict=None, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
-        """Evaluation-time value of the training objective (ExplicitDiT.py:80-137), forward only: per chunk the squared error
-        of the noise estimate for the (data_mean/std-normalised) label chunk, the previous chunk's model output as transition.
-        ``t`` (n_chunks, B), ``noise`` (n_chunks, B, fs*4) fix the draws."""
+        """The training objective (ExplicitDiT.py:80-137): per chunk the squared error of the noise estimate for the
+        (data_mean/std-normalised) label chunk, the previous chunk's model output as transition.  ``t`` (n_chunks, B),
+        ``noise`` (n_chunks, B, fs*4) fix the draws.  Differentiable when gradients are enabled (see TrajDiffusion.forward);
+        the value only under ``torch.no_grad()``."""
+        from . import train
+        if train.wants_grad(self.diffusion.diffusion):
+            return self._forward_impl(t, noise, kwargs)
+        with torch.no_grad():
+            return self._forward_impl(t, noise, kwargs)
+
+    def _forward_impl(self, t, noise, kwargs):
         from .refiner import LTMOutput
         trajectory_prior, maps_info = self._phase1(kwargs)
         trajectory_label = kwargs.get("trajectory_label", None)

@@ -247,3 +247,52 @@ def test_distributed_data_parallel_wraps_the_training_path(dev):
             assert torch.equal(a.grad, b.grad), n
     finally:
         dist.destroy_process_group()
+
+
+def test_explicit_wrapper_gradients(dev):
+    """ExplicitDiT.forward in gradient mode (flattened chunks: one token of fs*4 channels; each chunk's prediction is the next
+    chunk's transition, un-detached as in ExplicitDiT.py:107-114): loss and gradients against reverse-mode differentiation of
+    the same computation built from the oracle network.  (The wrapper's noise schedule is third-party: parity unpinned.)"""
+    from autodiffusion_amd import explicit, synth
+    from oracle import nets
+    fs, B = 20, 3
+    cfg = explicit.explicit_config(frame_stack=fs, num_train_timesteps=100, num_inference_steps=10)
+    m = explicit.ExplicitDiT(cfg)
+    synth.fill_module_(m.diffusion, WSEED)
+    with torch.no_grad():
+        m.init_x.copy_(synth.seeded_param("init_x", (fs * 4,), WSEED))
+    m = m.to(dev).train()
+    n_chunks, W = 80 // fs, fs * 4
+    maps, prior = synth.maps_info(B, ISEED), synth.trajectory_prior(B, ISEED)
+    label = prior + synth.noise(B, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    t = torch.from_numpy(np.random.default_rng(9).integers(1, 100, size=(n_chunks, B)).astype(np.int64))
+    noise = synth.noise(B, (n_chunks,), (W,), NSEED + 2)
+    out = m(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), trajectory_label=label.to(dev), t=t.to(dev), noise=noise.to(dev))
+    assert out.loss.requires_grad
+    out.loss.backward()
+    # CPU restatement of the same objective over the oracle network
+    sd = {k[len("diffusion.diffusion."):]: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
+          for k, v in m.state_dict().items() if k.startswith("diffusion.diffusion.")}
+    init_x = m.init_x.detach().cpu().clone().requires_grad_(True)
+    acp = torch.cumprod(1.0 - m.diffusion.betas.detach().cpu().float(), dim=0)
+    mean, std = m.data_mean.cpu(), m.data_std.cpu()
+    lab = ((label - mean) / std).reshape(B, n_chunks, W)
+    pri = prior.reshape(B, n_chunks, W)
+    transition = init_x[None].expand(B, W)
+    losses = []
+    for c in range(n_chunks):
+        a, s1 = acp[t[c]].sqrt()[:, None, None], (1.0 - acp[t[c]]).sqrt()[:, None, None]
+        x = a * lab[:, c, None, :] + s1 * noise[c][:, None, :]
+        pred = nets.variant_a_forward(sd, x, t[c], maps, transition[:, None, :], pri[:, c, None, :]).reshape(B, W)
+        losses.append((pred - noise[c]) ** 2)
+        transition = pred
+    ref = torch.stack(losses).mean()
+    ref.backward()
+    np.testing.assert_allclose(float(out.loss.detach()), float(ref.detach()), rtol=1e-4)
+    worst = max((l2_rel(p.grad, sd[n].grad), n) for n, p in m.diffusion.diffusion.named_parameters())
+    print("explicit wrapper: worst gradient error %.2e at %s" % worst)
+    assert worst[0] < GATE and l2_rel(m.init_x.grad, init_x.grad) < GATE
+    with torch.no_grad():
+        val = m(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), trajectory_label=label.to(dev), t=t.to(dev), noise=noise.to(dev))
+    assert not val.loss.requires_grad
+    np.testing.assert_allclose(float(val.loss), float(ref.detach()), rtol=1e-3)
