@@ -51,6 +51,44 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* x, const flo
     dx[i] = dy[i] * fmaf(v, pdf, cdf);
 }
 
+__global__ __launch_bounds__(256) void mul_kernel(const float* a, const float* b, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
+// The activations of the decoder twin (ADX_ACT_* codes): value and derivative with respect to the pre-activation.
+__device__ __forceinline__ float act_value(float v, int act) {
+    switch (act) {
+        case ADX_ACT_RELU: return fmaxf(v, 0.f);
+        case ADX_ACT_GELU_ERF: return 0.5f * v * erfcf(-v * 0.70710678118654752f);
+        case ADX_ACT_GELU_TANH: { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); return 0.5f * v * (1.0f + tanhf(u)); }
+        case ADX_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        case ADX_ACT_SILU: return v / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_slope(float v, int act) {
+    switch (act) {
+        case ADX_ACT_RELU: return v > 0.f ? 1.0f : 0.f;
+        case ADX_ACT_GELU_ERF: return fmaf(v, 0.3989422804014327f * expf(-0.5f * v * v), 0.5f * erfcf(-v * 0.70710678118654752f));
+        case ADX_ACT_GELU_TANH: {
+            const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v), th = tanhf(u);
+            return 0.5f * (1.0f + th) + 0.5f * v * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * v * v);
+        }
+        case ADX_ACT_LEAKY: return v > 0.f ? 1.0f : 0.01f;
+        case ADX_ACT_SILU: { const float sg = 1.0f / (1.0f + expf(-v)); return sg * (1.0f + v * (1.0f - sg)); }
+        default: return 1.0f;
+    }
+}
+__global__ __launch_bounds__(256) void act_kernel(const float* x, float* y, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = act_value(x[i], act);
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* x, const float* dy, float* dx, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = dy[i] * act_slope(x[i], act);
+}
+
 // d loss / d out for loss = mean_b( w[t_b] * mean_e (out - target)^2 ), times the upstream scalar gradient
 __global__ __launch_bounds__(256) void weighted_mse_bwd_kernel(const float* out, const float* target, const int64_t* t, const float* weight,
                                                                 const float* upstream, float* dout, int64_t total, int row_len, float inv_count) {
@@ -507,6 +545,33 @@ ADX_API int adx_op_add(const float* a, const float* b, float* out, int64_t n, vo
     return done(hipGetLastError(), "add");
 }
 
+ADX_API int adx_op_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return fail(ADX_EINVAL, "mul: null pointer or empty shape");
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return done(hipGetLastError(), "mul");
+}
+
+ADX_API int adx_op_act(const float* x, float* y, int64_t n, int act, void* stream) {
+    if (!x || !y || n <= 0) return fail(ADX_EINVAL, "act: null pointer or empty shape");
+    if (act < ADX_ACT_NONE || act > ADX_ACT_SILU) return fail(ADX_EINVAL, "act: unknown activation code");
+    hipLaunchKernelGGL(act_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
+    return done(hipGetLastError(), "act");
+}
+
+ADX_API int adx_op_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream) {
+    if (!x || !dy || !dx || n <= 0) return fail(ADX_EINVAL, "act_bwd: null pointer or empty shape");
+    if (act < ADX_ACT_NONE || act > ADX_ACT_SILU) return fail(ADX_EINVAL, "act_bwd: unknown activation code");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, act);
+    return done(hipGetLastError(), "act_bwd");
+}
+
+ADX_API int adx_op_group_colsum(const float* x, int G, int64_t R, int N, float* out, void* stream) {
+    if (!x || !out) return fail(ADX_EINVAL, "group_colsum: null pointer");
+    if (G <= 0 || G > 65535 || R <= 0 || N <= 0) return fail(ADX_EINVAL, "group_colsum: empty shape or more than 65535 groups");
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, G), dim3(256), 0, (hipStream_t)stream, x, (int64_t)G * R, N, R, out);
+    return done(hipGetLastError(), "group_colsum");
+}
+
 ADX_API int adx_op_gelu(const float* x, float* y, int64_t n, void* stream) {
     if (!x || !y || n <= 0) return fail(ADX_EINVAL, "gelu: null pointer or empty shape");
     hipLaunchKernelGGL(gelu_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
@@ -592,26 +657,30 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !stats) return fail(ADX_EINVAL, "attention_bwd: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_bwd: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_bwd: batch or head count above 65535");
-    constexpr int PT = 2;                                           // queries (keys) per thread
-    const dim3 gq((Sq + 128 * PT - 1) / (128 * PT), H, B), gk((Skv + 128 * PT - 1) / (128 * PT), H, B);
+    const int PTr = dh <= 16 ? 2 : 1;                               // queries (keys) per thread: 2 while the registers allow it
+    const dim3 gq((Sq + 128 * PTr - 1) / (128 * PTr), H, B), gk((Skv + 128 * PTr - 1) / (128 * PTr), H, B);
     hipStream_t s = (hipStream_t)stream;
+#define PT (DH_ <= 16 ? 2 : 1)
 #define ADX_ATTN_BWD3(DH, MASKED, LSE)                                                                                                                  \
     hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE>), gq, dim3(128), 0, s, q, k, v, o, dout, H, Sq, Skv, scale, mask_off, dq, stats);  \
     hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED>), gk, dim3(128), 0, s, q, k, v, dout, stats, H, Sq, Skv, scale, mask_off, dk, dv);
 #define ADX_ATTN_BWD2(DH, MASKED) if (stats_have_lse) { ADX_ATTN_BWD3(DH, MASKED, true) } else { ADX_ATTN_BWD3(DH, MASKED, false) }
 #define ADX_ATTN_BWD(DH)                                              \
-    case DH:                                                          \
+    case DH: {                                                        \
+        constexpr int DH_ = DH;                                       \
         if (mask_off < 0) { ADX_ATTN_BWD2(DH, false) } else { ADX_ATTN_BWD2(DH, true) } \
-        break;
+        break; }
     switch (dh) {
         ADX_ATTN_BWD(4)
         ADX_ATTN_BWD(8)
         ADX_ATTN_BWD(16)
-        default: return fail(ADX_EINVAL, "attention_bwd: head width must be 4, 8 or 16");
+        ADX_ATTN_BWD(32)
+        default: return fail(ADX_EINVAL, "attention_bwd: head width must be 4, 8, 16 or 32");
     }
 #undef ADX_ATTN_BWD
 #undef ADX_ATTN_BWD2
 #undef ADX_ATTN_BWD3
+#undef PT
     return done(hipGetLastError(), "attention_bwd");
 }
 
@@ -620,19 +689,21 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
     if (!q || !k || !v || !o || !stats) return fail(ADX_EINVAL, "attention_stats: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_stats: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_stats: batch or head count above 65535");
-    constexpr int PT = 2;
-    const dim3 gq((Sq + 128 * PT - 1) / (128 * PT), H, B);
+    const int PTr = dh <= 16 ? 2 : 1;
+    const dim3 gq((Sq + 128 * PTr - 1) / (128 * PTr), H, B);
     hipStream_t s = (hipStream_t)stream;
 #define ADX_ATTN_FWD(DH)                                                                                                                         \
-    case DH:                                                                                                                                     \
+    case DH: {                                                                                                                                   \
+        constexpr int PT = DH <= 16 ? 2 : 1;                                                                                                     \
         if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false>), gq, dim3(128), 0, s, q, k, v, H, Sq, Skv, scale, mask_off, o, stats); \
         else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true>), gq, dim3(128), 0, s, q, k, v, H, Sq, Skv, scale, mask_off, o, stats);     \
-        break;
+        break; }
     switch (dh) {
         ADX_ATTN_FWD(4)
         ADX_ATTN_FWD(8)
         ADX_ATTN_FWD(16)
-        default: return fail(ADX_EINVAL, "attention_stats: head width must be 4, 8 or 16");
+        ADX_ATTN_FWD(32)
+        default: return fail(ADX_EINVAL, "attention_stats: head width must be 4, 8, 16 or 32");
     }
 #undef ADX_ATTN_FWD
     return done(hipGetLastError(), "attention_stats");

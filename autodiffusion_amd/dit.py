@@ -211,12 +211,21 @@ class DiffusionWrapper(nn.Module):
         assert batch_size > 0
         return self.sample_forward(hidden_state, batch_size, info_dict=info_dict, get_inter=get_inter, **kwargs)
 
-    @torch.no_grad()
     def train_forward(self, hidden_state, trajectory_label, info_dict=None, t: Optional[torch.Tensor] = None,
                       noise: Optional[torch.Tensor] = None):
-        """Forward-only value of the training loss (diffusion_decoder.py:346-365): normalise the label, q_sample at one random
-        timestep per row, one denoiser call; returns the element-wise squared error (B, S, C) as the reference does."""
-        from . import ops
+        """The training loss (diffusion_decoder.py:346-365): normalise the label, q_sample at one random timestep per row, one
+        denoiser call; returns the element-wise squared error (B, S, C) as the reference does.  With gradients enabled, trainable
+        parameters and the DiT backbone the denoiser call is the differentiable training path (``train.py``; gradients also reach
+        ``hidden_state`` when it requires them); otherwise (``torch.no_grad()``, or the MM-DiT backbone) only the value."""
+        from . import train
+        grad = train.wants_grad(self.model) and self.model.config.diffusion_backbone == "DiT"
+        if grad:
+            return self._train_forward(hidden_state, trajectory_label, info_dict, t, noise, True)
+        with torch.no_grad():
+            return self._train_forward(hidden_state, trajectory_label, info_dict, t, noise, False)
+
+    def _train_forward(self, hidden_state, trajectory_label, info_dict, t, noise, grad: bool):
+        from . import ops, train
         x0 = ops.normalize(_lib.f32c(trajectory_label))
         B = x0.shape[0]
         if t is None:
@@ -224,7 +233,10 @@ class DiffusionWrapper(nn.Module):
         t = t.to(device=x0.device, dtype=torch.int64).contiguous()
         noise = torch.randn_like(x0) if noise is None else _lib.f32c(noise)
         x_noisy, _ = ops.q_sample(x0, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
-        x_recon = self.model(x_noisy, t, hidden_state, info_dict=info_dict)
+        if grad:
+            x_recon = train.denoise_dit_with_grad(self.model, x_noisy, t, hidden_state)
+        else:
+            x_recon = self.model(x_noisy, t, hidden_state, info_dict=info_dict)
         return (x_recon - noise) ** 2
 
     @torch.no_grad()
@@ -299,11 +311,11 @@ class DiffusionDecoder(nn.Module):
         self.model = DiffusionWrapper(net, beta_schedule=config.beta_schedule, n_timesteps=config.diffusion_timesteps,
                                       predict_range=self.predict_range)
 
-    @torch.no_grad()
     def forward(self, label, hidden_output, info_dict=None, device=None, t: Optional[torch.Tensor] = None,
                 noise: Optional[torch.Tensor] = None):
         """-> (loss, logits): summed squared error of the noise estimate times ``trajectory_loss_rescale`` and all-zero logits
-        (diffusion_decoder.py:502-532), forward only."""
+        (diffusion_decoder.py:502-532).  Differentiable for the DiT backbone when gradients are enabled (see
+        DiffusionWrapper.train_forward); the value only otherwise."""
         if not self.config.predict_yaw:
             label = label[..., :2].clone()
         loss = self.model.train_forward(hidden_output, label, info_dict=info_dict, t=t, noise=noise).sum()

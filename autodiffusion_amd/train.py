@@ -374,3 +374,206 @@ def denoise_with_grad(module: torch.nn.Module, x, t, condition: Dict[str, torch.
 
 def wants_grad(module: torch.nn.Module) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+# ================================================================================================ decoder twin (DiT backbone)
+# Transformer_TrajDiffusionModel.forward (diffusion_decoder.py:251-277) with DiTBlock / DiT_FinalLayer
+# (libs/diffusionTransformer.py:24-53, 182-199) and DecoderResCat (libs/mlp.py:43-55) under the same scheme: forward with kept
+# activations, backward through the library's operators.  fp32; the MM-DiT backbone has no backward here.
+def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    a, b = f32c(a), f32c(b)
+    if a.shape != b.shape:
+        raise ValueError("mul: shapes differ")
+    out = torch.empty_like(a)
+    check(_lib.load().adx_op_mul(ptr(a), ptr(b), ptr(out), a.numel(), current_stream()), "mul")
+    return out
+
+
+def act(x: torch.Tensor, code: int) -> torch.Tensor:
+    x = f32c(x)
+    y = torch.empty_like(x)
+    check(_lib.load().adx_op_act(ptr(x), ptr(y), x.numel(), int(code), current_stream()), "act")
+    return y
+
+
+def act_bwd(x: torch.Tensor, dy: torch.Tensor, code: int) -> torch.Tensor:
+    x, dy = f32c(x), f32c(dy)
+    dx = torch.empty_like(x)
+    check(_lib.load().adx_op_act_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), int(code), current_stream()), "act_bwd")
+    return dx
+
+
+def group_colsum(x: torch.Tensor) -> torch.Tensor:
+    """(G, R, N) -> (G, N): sum over the middle axis."""
+    x = f32c(x)
+    G, R, N = x.shape
+    out = torch.empty(G, N, device=x.device, dtype=torch.float32)
+    check(_lib.load().adx_op_group_colsum(ptr(x), G, R, N, ptr(out), current_stream()), "group_colsum")
+    return out
+
+
+def _res_cat(P, prefix: str, x):
+    h0 = _lin(P, x, prefix + "mlp.linear.")
+    h1 = ops.layernorm(h0, P[prefix + "mlp.layer_norm.weight"], P[prefix + "mlp.layer_norm.bias"], eps=1e-5)
+    cat = torch.cat([x, act(h1, _lib.ACT_RELU)], dim=-1)
+    return _lin(P, cat, prefix + "fc."), (x, h0, h1, cat)
+
+
+def _res_cat_bwd(P, G, prefix: str, saved, dout, need_dx: bool = True):
+    x, h0, h1, cat = saved
+    n_in = x.shape[-1]
+    dcat = _lin_bwd(P, G, dout, cat, prefix + "fc.")
+    dh1 = act_bwd(h1, dcat[..., n_in:].contiguous(), _lib.ACT_RELU)
+    dh0 = _ln_bwd(P, G, h0, dh1, prefix + "mlp.layer_norm.")
+    dxa = _lin_bwd(P, G, dh0, x, prefix + "mlp.linear.", need_dx=need_dx)
+    return add(dcat[..., :n_in].contiguous(), dxa) if need_dx else None
+
+
+def _modulate(x, shift, scale):
+    return ops.layernorm(x, None, None, shift, scale, eps=1e-6)
+
+
+def _modulate_bwd(x, scale, dy):
+    """y = LN0(x) (1 + scale) + shift -> (dx, dshift, dscale)."""
+    n = ops.layernorm(x, eps=1e-6)
+    dn = add(dy, mul(dy, scale))
+    dx, _ = layernorm_bwd(x, None, dn, 1e-6, want_dy_xhat=False)
+    return dx, dy, mul(dy, n)
+
+
+def _post_norm_layer(P, prefix: str, z, n_head: int):
+    a, sa = _mha(P, prefix + "self_attn.", z, z, n_head, -1)
+    r1 = add(z, a)
+    z1 = _norm(P, prefix + "norm1.", r1)
+    p = _lin(P, z1, prefix + "linear1.")
+    pa = act(p, _lib.ACT_RELU)
+    r2 = add(z1, _lin(P, pa, prefix + "linear2."))
+    return _norm(P, prefix + "norm2.", r2), (z, sa, r1, z1, p, pa, r2)
+
+
+def _post_norm_layer_bwd(P, G, prefix: str, saved, dz2, n_head: int):
+    z, sa, r1, z1, p, pa, r2 = saved
+    dr2 = _ln_bwd(P, G, r2, dz2, prefix + "norm2.")
+    dp = act_bwd(p, _lin_bwd(P, G, dr2, pa, prefix + "linear2."), _lib.ACT_RELU)
+    dz1 = add(dr2, _lin_bwd(P, G, dp, z1, prefix + "linear1."))
+    dr1 = _ln_bwd(P, G, r1, dz1, prefix + "norm1.")
+    dq, dkv = _mha_bwd(P, G, prefix + "self_attn.", z, z, sa, dr1, n_head, -1)
+    return add(dr1, add(dq, dkv))
+
+
+def _dit_block(P, prefix: str, h, silu_c, n_head: int):
+    mod = _lin(P, silu_c, prefix + "adaLN_modulation.1.")
+    sh_a, sc_a, g_a, sh_m, sc_m, g_m = (m.contiguous() for m in mod.chunk(6, dim=-1))
+    h1 = _modulate(h, sh_a, sc_a)
+    e, se = _post_norm_layer(P, prefix + "attn.", h1, n_head)
+    hA = add(h, mul(g_a, e))
+    h2 = _modulate(hA, sh_m, sc_m)
+    u = _lin(P, h2, prefix + "mlp.0.")
+    ua = act(u, _lib.ACT_GELU_TANH)
+    w = _lin(P, ua, prefix + "mlp.2.")
+    wa = act(w, _lib.ACT_GELU_TANH)
+    return add(hA, mul(g_m, wa)), (h, sc_a, g_a, se, e, hA, sc_m, g_m, h2, u, ua, w, wa)
+
+
+def _dit_block_bwd(P, G, prefix: str, saved, silu_c, dout, n_head: int):
+    h, sc_a, g_a, se, e, hA, sc_m, g_m, h2, u, ua, w, wa = saved
+    dg_m = mul(dout, wa)
+    dw = act_bwd(w, mul(dout, g_m), _lib.ACT_GELU_TANH)
+    du = act_bwd(u, _lin_bwd(P, G, dw, ua, prefix + "mlp.2."), _lib.ACT_GELU_TANH)
+    dhA_mod, dsh_m, dsc_m = _modulate_bwd(hA, sc_m, _lin_bwd(P, G, du, h2, prefix + "mlp.0."))
+    dhA = add(dout, dhA_mod)
+    dg_a = mul(dhA, e)
+    dh1 = _post_norm_layer_bwd(P, G, prefix + "attn.", se, mul(dhA, g_a), n_head)
+    dh_mod, dsh_a, dsc_a = _modulate_bwd(h, sc_a, dh1)
+    dmod = torch.cat([dsh_a, dsc_a, dg_a, dsh_m, dsc_m, dg_m], dim=-1)
+    return add(dhA, dh_mod), _lin_bwd(P, G, dmod, silu_c, prefix + "adaLN_modulation.1.")
+
+
+def dit_forward(P: Dict[str, torch.Tensor], x, t, state, n_head: int, n_blocks: int, n_state: int, n_x: int):
+    d = P["position_embedding"].shape[-1]
+    B, S = x.shape[0], x.shape[1]
+    tape: Dict[str, object] = {}
+    s, st_saved = state, []
+    for i in range(n_state):
+        s, sv = _res_cat(P, f"state_encoder.{i}.", s)
+        st_saved.append(sv)
+    xe, x_saved = x, []
+    for i in range(n_x):
+        xe, sv = _res_cat(P, f"x_encoder.{i}.", xe)
+        x_saved.append(sv)
+    emb = ops.timestep_embedding(t, d)
+    a1 = _lin(P, emb, "time_encoder.1.")
+    b1 = act(a1, _lib.ACT_LEAKY)
+    a2 = _lin(P, b1, "time_encoder.3.")
+    b2 = act(a2, _lib.ACT_LEAKY)
+    te = _lin(P, b2, "time_encoder.5.")
+    h = add(xe, P["position_embedding"].reshape(1, -1, d)[:, :S].expand(B, S, d).contiguous())
+    c = add(te[:, None, :].expand(B, S, d).contiguous(), s)
+    silu_c = act(c, _lib.ACT_SILU)
+    blocks = []
+    for i in range(n_blocks):
+        h, sv = _dit_block(P, f"blocks.{i}.", h, silu_c, n_head)
+        blocks.append(sv)
+    mod = _lin(P, silu_c, "final_layer.adaLN_modulation.1.")
+    sh, sc = (m.contiguous() for m in mod.chunk(2, dim=-1))
+    hf = _modulate(h, sh, sc)
+    out = _lin(P, hf, "final_layer.linear.")
+    tape.update(st=st_saved, xs=x_saved, time=(emb, a1, b1, a2, b2), c=c, silu_c=silu_c, blocks=blocks, h=h, sc=sc, hf=hf, S=S)
+    return out, tape
+
+
+def dit_backward(P: Dict[str, torch.Tensor], tape, dout, n_head: int, want_state_grad: bool = False):
+    G = _Grads(P)
+    silu_c = tape["silu_c"]
+    dhf = _lin_bwd(P, G, f32c(dout), tape["hf"], "final_layer.linear.")
+    dh, dsh, dsc = _modulate_bwd(tape["h"], tape["sc"], dhf)
+    dsilu = _lin_bwd(P, G, torch.cat([dsh, dsc], dim=-1), silu_c, "final_layer.adaLN_modulation.1.")
+    for i in reversed(range(len(tape["blocks"]))):
+        dh, ds_i = _dit_block_bwd(P, G, f"blocks.{i}.", tape["blocks"][i], silu_c, dh, n_head)
+        dsilu = add(dsilu, ds_i)
+    dc = act_bwd(tape["c"], dsilu, _lib.ACT_SILU)
+    # c = time embedding (broadcast over the tokens) + state embedding
+    dte = group_colsum(dc)
+    emb, a1, b1, a2, b2 = tape["time"]
+    da2 = act_bwd(a2, _lin_bwd(P, G, dte, b2, "time_encoder.5."), _lib.ACT_LEAKY)
+    da1 = act_bwd(a1, _lin_bwd(P, G, da2, b1, "time_encoder.3."), _lib.ACT_LEAKY)
+    _lin_bwd(P, G, da1, emb, "time_encoder.1.", need_dx=False)
+    ds = dc
+    for i in reversed(range(len(tape["st"]))):
+        ds = _res_cat_bwd(P, G, f"state_encoder.{i}.", tape["st"][i], ds, need_dx=(i > 0 or want_state_grad))
+    # h0 = x embedding + position table
+    colsum(dh, _slice_rows(G.of("position_embedding").reshape(1, -1, dh.shape[-1]), tape["S"]))
+    dx = dh
+    for i in reversed(range(len(tape["xs"]))):
+        dx = _res_cat_bwd(P, G, f"x_encoder.{i}.", tape["xs"][i], dx, need_dx=i > 0)
+    return G.g, ds
+
+
+class DenoiserDiT(torch.autograd.Function):
+    """``Transformer_TrajDiffusionModel.forward`` (DiT backbone) as a differentiable function of its parameters and of ``state``."""
+
+    @staticmethod
+    def forward(ctx, meta, x, t, state, *params):
+        names, n_head, n_blocks, n_state, n_x = meta
+        P = {n: p.detach() for n, p in zip(names, params)}
+        out, tape = dit_forward(P, f32c(x), t, f32c(state), n_head, n_blocks, n_state, n_x)
+        ctx.meta, ctx.P, ctx.tape = meta, P, tape
+        ctx.want_state = bool(ctx.needs_input_grad[3])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        names, n_head = ctx.meta[0], ctx.meta[1]
+        grads, d_state = dit_backward(ctx.P, ctx.tape, dout.contiguous(), n_head, ctx.want_state)
+        ctx.tape = None
+        return (None, None, None, d_state) + tuple(grads.get(n) for n in names)
+
+
+def denoise_dit_with_grad(module: torch.nn.Module, x, t, state) -> torch.Tensor:
+    """Differentiable call of a ``dit.Transformer_TrajDiffusionModel`` with the DiT backbone."""
+    if module.config.diffusion_backbone != "DiT":
+        raise NotImplementedError("the training path covers the DiT backbone; MM-DiT has no backward")
+    named = [(n, p) for n, p in module.named_parameters()]
+    meta = (tuple(n for n, _ in named), int(module.config.n_head), len(module.blocks), len(list(module.state_encoder.children())),
+            len(list(module.x_encoder.children())))
+    return DenoiserDiT.apply(meta, x, t, state, *[p for _, p in named])

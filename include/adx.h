@@ -230,6 +230,15 @@ int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t,
  * ------------------------------------------------------------------------------------------ */
 int adx_op_add(const float* a, const float* b, float* out, int64_t n, void* stream);              /* residual adds, gradient sums */
 int adx_op_transpose(const float* x, float* y, int rows, int cols, void* stream);                 /* y[cols][rows] = x^T */
+int adx_op_mul(const float* a, const float* b, float* out, int64_t n, void* stream);              /* gates, modulation: a * b */
+/* The activations of the decoder twin (ADX_ACT_* codes: ReLU of nn.TransformerEncoderLayer and DecoderResCat, tanh-GELU of
+ * the block MLPs, SiLU of adaLN, LeakyReLU(0.01) of the time encoder; libs/diffusionTransformer.py:24-53, libs/mlp.py:43-55,
+ * diffusion_decoder.py:126-145) as stand-alone operators, and dx = dy * act'(x) with x the pre-activation. */
+int adx_op_act(const float* x, float* y, int64_t n, int act, void* stream);
+int adx_op_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream);
+/* out[g][c] = sum over r of x[g][r][c] (x is [G][R][N], G <= 65535): the gradient of a per-item vector that the forward
+ * broadcast over the R tokens of an item (the time embedding added to every token's condition, diffusion_decoder.py:256). */
+int adx_op_group_colsum(const float* x, int G, int64_t R, int N, float* out, void* stream);
 /* F.gelu (erf form; activation of nn.TransformerEncoder/DecoderLayer, transformer.py:69-102) and its derivative:
  * dx = dy (Phi(x) + x phi(x)) with x the pre-activation. */
 int adx_op_gelu(const float* x, float* y, int64_t n, void* stream);
@@ -248,14 +257,14 @@ int adx_op_colsum(const float* x, int64_t M, int N, float* out, int accumulate, 
  * bias gradient is the column sum of dy).  gamma may be NULL (no affine). */
 int adx_op_layernorm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int d, float eps, float* dx,
                          float* dy_xhat, void* stream);
-/* Backward of adx_op_attention (same layouts and mask rule) for head widths 4, 8, 16 (dv == dh): o is the forward output,
+/* Backward of adx_op_attention (same layouts and mask rule) for head widths 4, 8, 16, 32 (dv == dh): o is the forward output,
  * dout its gradient; stats holds 2*B*H*Sq floats (per query and head: the log-sum-exp of the scores, base 2, and dout.o).
  * With stats_have_lse != 0 the log-sum-exps were written by adx_op_attention_stats and the pass that finds them is skipped;
  * otherwise stats is pure scratch.  Probabilities are recomputed, never stored. */
 int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H,
                          int Sq, int Skv, int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats,
                          int stats_have_lse, void* stream);
-/* adx_op_attention for a forward whose backward will follow (head widths 4, 8, 16, dv == dh, fp32): writes o and, in
+/* adx_op_attention for a forward whose backward will follow (head widths 4, 8, 16, 32, dv == dh, fp32): writes o and, in
  * stats[((b*H + h)*Sq + i)*2], the log-sum-exp of query i's scores. */
 int adx_op_attention_stats(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq,
                            int Skv, int dh, float scale, int mask_off, void* stream);

@@ -102,7 +102,7 @@ def test_op_layernorm_bwd(dev, rows, d):
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,dh,mask_off", [(2, 8, 809, 809, 4, -1), (3, 8, 10, 10, 4, 0), (3, 8, 10, 809, 4, 1), (2, 8, 80, 949, 4, 1),
-                                                   (1, 2, 130, 257, 8, -1), (2, 4, 33, 33, 16, 0)])
+                                                   (1, 2, 130, 257, 8, -1), (2, 4, 33, 33, 16, 0), (2, 8, 80, 80, 32, -1), (1, 3, 200, 140, 32, 2)])
 def test_op_attention_bwd(dev, B, H, Sq, Skv, dh, mask_off):
     from autodiffusion_amd import ops, train
     from oracle import nets
@@ -296,3 +296,64 @@ def test_explicit_wrapper_gradients(dev):
         val = m(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), trajectory_label=label.to(dev), t=t.to(dev), noise=noise.to(dev))
     assert not val.loss.requires_grad
     np.testing.assert_allclose(float(val.loss), float(ref.detach()), rtol=1e-3)
+
+
+@pytest.mark.parametrize("code", [1, 2, 3, 4, 5])
+def test_op_activations_mul_group_colsum(dev, code):
+    from autodiffusion_amd import train
+    fns = {1: torch.relu, 2: torch.nn.functional.gelu, 3: lambda v: torch.nn.functional.gelu(v, approximate="tanh"),
+           4: lambda v: torch.nn.functional.leaky_relu(v, 0.01), 5: torch.nn.functional.silu}
+    g = torch.Generator().manual_seed(code)
+    x = (torch.randn(5000, generator=g) * 3).double().requires_grad_(True)
+    dy = torch.randn(5000, generator=g)
+    y = fns[code](x)
+    y.backward(dy.double())
+    assert rel_err(train.act(x.detach().float().to(dev), code).cpu(), y.detach()) < 3e-6
+    assert rel_err(train.act_bwd(x.detach().float().to(dev), dy.to(dev), code).cpu(), x.grad) < 3e-6
+    a, b = torch.randn(7, 80, 33, generator=g), torch.randn(7, 80, 33, generator=g)
+    assert torch.equal(train.mul(a.to(dev), b.to(dev)).cpu(), a * b)
+    assert l2_rel(train.group_colsum(a.to(dev)), a.double().sum(1)) < 2e-6
+
+
+def check_grad_fixture(g, grads, tol):
+    seen = 0
+    for k, v in g.items():
+        kind, _, name = k.partition(".")
+        if kind == "grad":
+            assert l2_rel(grads[name].reshape(-1), v) < tol, name
+        elif kind == "gradnorm":
+            flat = grads[name].reshape(-1)
+            sample = g["gradsample." + name]
+            assert abs(float(flat.norm()) - float(v)) < tol * float(v), name
+            assert l2_rel(flat[::flat.numel() // 1024][:sample.shape[0]], sample) < tol, name
+        else:
+            continue
+        seen += 1
+    return seen
+
+
+def test_decoder_twin_gradients_match_the_reference(dev, golden):
+    """loss.backward() through DiffusionDecoder.forward (DiT backbone, hidden 64, 2 blocks, 4 heads) on the HIP training path
+    against the gradients of the reference's own backward(): every parameter tensor and the backbone hidden state."""
+    from autodiffusion_amd import dit, synth
+    g = golden("g15_twin_grads")
+    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "DiT", diffusion_timesteps=10))
+    synth.fill_module_(dec, WSEED)
+    dec = dec.to(dev).train()
+    state = synth.hidden_state(2, 64, ISEED).to(dev).requires_grad_(True)
+    label = (synth.trajectory_prior(2, ISEED) + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])).to(dev)
+    loss, logits = dec(label, state, t=T(g["t"]).to(dev), noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
+    assert loss.requires_grad and not logits.any()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4)
+    loss.backward()
+    grads = {n: p.grad for n, p in dec.model.model.named_parameters() if p.grad is not None}
+    n = check_grad_fixture(g, grads, GATE)
+    assert n == len(grads) and n > 60
+    assert l2_rel(state.grad, g["grad_state"]) < GATE
+    with torch.no_grad():
+        val, _ = dec(label, state, t=T(g["t"]).to(dev), noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
+    assert not val.requires_grad
+    np.testing.assert_allclose(float(val), float(g["loss"]), rtol=1e-3)
+    # the MM-DiT backbone has no backward: its loss is a value
+    mm = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "MM-DiT", diffusion_timesteps=10)).to(dev).train()
+    assert not mm(label, state.detach())[0].requires_grad

@@ -438,6 +438,40 @@ def test_refiner_loss_gradients(golden):
         assert grad_rel_err(grads[k], v) < 2e-4, k
 
 
+def check_grad_fixture(g, grads, tol, rel=grad_rel_err):
+    """Gradients by parameter name against a fixture written by make_golden.grad_record (whole tensors, or norm + strided sample)."""
+    seen = 0
+    for k, v in g.items():
+        kind, _, name = k.partition(".")
+        if kind == "grad":
+            assert rel(grads[name].reshape(-1), v) < tol, name
+        elif kind == "gradnorm":
+            flat = grads[name].reshape(-1)
+            sample = g["gradsample." + name]
+            assert abs(float(flat.norm()) - float(v)) < tol * float(v), name
+            assert rel(flat[::flat.numel() // 1024][:sample.shape[0]], sample) < tol, name
+        else:
+            continue
+        seen += 1
+    return seen
+
+
+def test_twin_loss_gradients(golden):
+    """Reverse-mode gradients of the restated decoder-twin loss (DiT backbone) against the reference's own backward()."""
+    g = golden("g15_twin_grads")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in dit_sd(64, 2, 4, "DiT", prefix="model.model.").items()}
+    state = synth.hidden_state(2, 64, ISEED).requires_grad_(True)
+    label = synth.trajectory_prior(2, ISEED) + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    b = schedules.buffers_from_betas(schedules.twin_betas("cosine", 10), f32=True)
+    loss = sampling.twin_loss(lambda x, t: nets.dit_forward(sd, x, t, state, 4, "DiT"), b, label, T(g["t"]),
+                              synth.noise(2, (), (80, 4), NSEED + 2)).sum()
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=2e-5)
+    n = check_grad_fixture(g, {k: v.grad for k, v in sd.items() if v.grad is not None}, 2e-4)
+    assert n == len([k for k in sd if sd[k].grad is not None]) and n > 60
+    assert grad_rel_err(state.grad, g["grad_state"]) < 2e-4
+
+
 @pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
 def test_twin_forward_loss(golden, backbone):
     g = golden("g13_forward_loss")
