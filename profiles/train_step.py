@@ -54,7 +54,7 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         assert bool(torch.isfinite(loss))
         line = {"workload": f"refiner training step, frame_stack {fs} x {80 // fs} chunks, {obj}, {sched}, N={N}, B={B}, fp32",
-                "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1), "denoiser_fwd_bwd_per_step": 80 // fs, "loss": float(loss)}
+                "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(B / dt, 1), "denoiser_fwd_bwd_per_step": 80 // fs, "loss": float(loss.detach())}
         if args.cpu:
             from oracle import nets, sampling, schedules
             sd = {k[len("diffusion.diffusion.model."):]: v.detach().float().cpu() for k, v in da.state_dict().items()
@@ -70,6 +70,36 @@ def main():
             line["cpu_autograd"] = {"ms_per_chunk": round(dc * 1e3, 1), "samples_per_s": round(B / (dc * (80 // fs)), 2),
                                     "threads": torch.get_num_threads(), "sample": "1 chunk forward + backward of the fp32 oracle, whole step = chunks x that"}
         print(json.dumps(line), flush=True)
+    if not args.only or args.only == "dit256":
+        # decoder twin, DiT backbone as ldr_diffusion.yaml sizes it (hidden 256, 4 blocks, 8 heads), the reference's debug batch of 32
+        from autodiffusion_amd import dit
+        Bd = min(B, 32)
+        dec = dit.DiffusionDecoder(dit.dit_config(256, 4, 8, "DiT", diffusion_timesteps=10))
+        with torch.no_grad():
+            for p in dec.parameters():
+                p.normal_(0.0, 0.02)
+        dec = dec.to(dev).train()
+        state = synth.hidden_state(Bd, 256, 7).to(dev)
+        label = synth.trajectory_prior(Bd, 7).to(dev)
+        opt = torch.optim.SGD(dec.parameters(), lr=1e-9)      # timing only: the summed loss of random weights has gradients of norm 1e4
+
+        def dstep():
+            opt.zero_grad(set_to_none=True)
+            loss, _ = dec(label, state)
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(3):
+            loss = dstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = dstep()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        assert bool(torch.isfinite(loss.detach()))
+        print(json.dumps({"workload": f"DiT decoder twin training step, hidden 256, 4 blocks, 8 heads, B={Bd}, fp32",
+                          "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(Bd / dt, 1)}), flush=True)
 
 
 if __name__ == "__main__":
