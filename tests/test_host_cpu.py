@@ -346,3 +346,30 @@ def test_mlp256_rejects_mismatched_operands():
         ops.mlp256(torch.zeros(128, 128), w1, None, 1, w2, None)     # not 256 wide
     with pytest.raises(ValueError):
         ops.mlp256(x, w1, None, 1, w2, None, res=torch.zeros(127, 256))
+
+
+def test_training_path_host_logic():
+    """The training path's host side without a GPU: the mode switch (gradients enabled and trainable parameters), the refusal of
+    host tensors (there is no CPU fallback), and the flat gradient store that hands out zero-filled views by parameter name."""
+    import torch
+    from autodiffusion_amd import _lib, refiner, train
+    tr = refiner.TrajectoryRefiner(refiner.refiner_config(frame_stack=10, diffusion_timesteps=10))
+    net = tr.diffusion.model
+    assert train.wants_grad(net)
+    with torch.no_grad():
+        assert not train.wants_grad(net)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    assert not train.wants_grad(net)
+    names = train.trainable_names(net)
+    assert len(names) == 108 and "cond_pos_emb" in names and "decoder.layers.3.multihead_attn.in_proj_weight" in names
+    with pytest.raises(_lib.AdxError, match="device memory"):
+        train.add(torch.zeros(4), torch.zeros(4))
+    with pytest.raises(ValueError):
+        train.add(torch.zeros(4), torch.zeros(5))
+    params = {"a.weight": torch.ones(3, 2), "a.bias": torch.ones(3)}
+    g = train._Grads(params)
+    w = g.of("a.weight")
+    assert w.shape == (3, 2) and not w.any() and g.of("a.weight") is w and g.of("a.bias").shape == (3,)
+    w += 1
+    assert float(g.flat.sum()) == 6.0 and set(g.g) == {"a.weight", "a.bias"}
