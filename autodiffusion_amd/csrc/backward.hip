@@ -524,6 +524,131 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------ short sequences, wide heads
+// The joint attention of the MM-DiT blocks (80 tokens, head width 2 d = 128 ... 512; libs/diffusionTransformer.py:99-117): one
+// workgroup per (item, head), the Sq x Skv probability matrix lives in LDS (and in the backward a second matrix for dS), the
+// head dimension is walked with 16-byte loads.  Scores in base 2: the statistics are those of attn_fwd_stats_kernel.
+__device__ __forceinline__ float dot_rows(const float* a, const float* b, int DH) {
+    float s = 0.f;
+    for (int e = 0; e < DH; e += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(a + e), y = *reinterpret_cast<const float4*>(b + e);
+        s = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s))));
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const float* q, const float* k, const float* v, int H, int Sq, int Skv, int DH,
+                                                             float scale, int mask_off, float* o, float* stats) {
+    extern __shared__ float wide_lds[];
+    float* P = wide_lds;                                            // [Sq][Skv + 1]
+    const int b = blockIdx.y, h = blockIdx.x, ld = H * DH, ldp = Skv + 1;
+    const float* qb = q + (int64_t)b * Sq * ld + h * DH;
+    const float* kb = k + (int64_t)b * Skv * ld + h * DH;
+    const float* vb = v + (int64_t)b * Skv * ld + h * DH;
+    for (int idx = threadIdx.x; idx < Sq * Skv; idx += 256) {
+        const int i = idx / Skv, j = idx % Skv;
+        const bool vis = mask_off < 0 || j <= i + mask_off;
+        P[i * ldp + j] = vis ? dot_rows(qb + (int64_t)i * ld, kb + (int64_t)j * ld, DH) * (scale * kLog2e) : -INFINITY;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < Sq; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < Skv; j += 64) m = fmaxf(m, P[i * ldp + j]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float l = 0.f;
+        for (int j = lane; j < Skv; j += 64) { const float p = exp2_raw(P[i * ldp + j] - m); P[i * ldp + j] = p; l += p; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+        const float inv = 1.0f / l;
+        for (int j = lane; j < Skv; j += 64) P[i * ldp + j] *= inv;
+        if (lane == 0) stats[(((int64_t)b * H + h) * Sq + i) * 2] = m + log2f(l);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Sq * DH; idx += 256) {
+        const int i = idx / DH, e = idx % DH;
+        float acc = 0.f;
+        for (int j = 0; j < Skv; ++j) acc = fmaf(P[i * ldp + j], vb[(int64_t)j * ld + e], acc);
+        o[((int64_t)b * Sq + i) * ld + h * DH + e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_wide_bwd_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
+                                                             float* stats, int have_lse, int H, int Sq, int Skv, int DH, float scale, int mask_off,
+                                                             float* dq, float* dk, float* dv) {
+    extern __shared__ float wide_lds[];
+    const int b = blockIdx.y, h = blockIdx.x, ld = H * DH, ldp = Skv + 1;
+    float* P = wide_lds;                                            // [Sq][Skv + 1]
+    float* dS = P + Sq * ldp;                                       // [Sq][Skv + 1]
+    float* Dv = dS + Sq * ldp;                                      // [Sq]: dout . o
+    float* Ls = Dv + Sq;                                            // [Sq]: log-sum-exp
+    const float* qb = q + (int64_t)b * Sq * ld + h * DH;
+    const float* kb = k + (int64_t)b * Skv * ld + h * DH;
+    const float* vb = v + (int64_t)b * Skv * ld + h * DH;
+    const float* ob = o + (int64_t)b * Sq * ld + h * DH;
+    const float* gb = dout + (int64_t)b * Sq * ld + h * DH;
+    float* st = stats + ((int64_t)b * H + h) * Sq * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int idx = threadIdx.x; idx < Sq * Skv; idx += 256) {
+        const int i = idx / Skv, j = idx % Skv;
+        const bool vis = mask_off < 0 || j <= i + mask_off;
+        P[i * ldp + j] = vis ? dot_rows(qb + (int64_t)i * ld, kb + (int64_t)j * ld, DH) * (scale * kLog2e) : -INFINITY;
+        dS[i * ldp + j] = dot_rows(gb + (int64_t)i * ld, vb + (int64_t)j * ld, DH);
+    }
+    __syncthreads();
+    for (int i = wave; i < Sq; i += 4) {
+        float lse;
+        if (have_lse) {
+            lse = st[i * 2];
+        } else {
+            float m = -INFINITY;
+            for (int j = lane; j < Skv; j += 64) m = fmaxf(m, P[i * ldp + j]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float l = 0.f;
+            for (int j = lane; j < Skv; j += 64) l += exp2_raw(P[i * ldp + j] - m);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+            lse = m + log2f(l);
+        }
+        float d = 0.f;
+        for (int e = lane; e < DH; e += 64) d = fmaf(gb[(int64_t)i * ld + e], ob[(int64_t)i * ld + e], d);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        for (int j = lane; j < Skv; j += 64) {
+            const float p = exp2_raw(P[i * ldp + j] - lse);
+            P[i * ldp + j] = p;
+            dS[i * ldp + j] = p * (dS[i * ldp + j] - d);
+        }
+        if (lane == 0) { st[i * 2] = lse; st[i * 2 + 1] = d; }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Sq * DH; idx += 256) {
+        const int i = idx / DH, e = idx % DH;
+        float acc = 0.f;
+        for (int j = 0; j < Skv; ++j) acc = fmaf(dS[i * ldp + j], kb[(int64_t)j * ld + e], acc);
+        dq[((int64_t)b * Sq + i) * ld + h * DH + e] = acc * scale;
+    }
+    for (int idx = threadIdx.x; idx < Skv * DH; idx += 256) {
+        const int j = idx / DH, e = idx % DH;
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < Sq; ++i) {
+            ak = fmaf(dS[i * ldp + j], qb[(int64_t)i * ld + e], ak);
+            av = fmaf(P[i * ldp + j], gb[(int64_t)i * ld + e], av);
+        }
+        dk[((int64_t)b * Skv + j) * ld + h * DH + e] = ak * scale;
+        dv[((int64_t)b * Skv + j) * ld + h * DH + e] = av;
+    }
+}
+
+// bytes of LDS the wide-head kernels need (forward: one matrix; backward: two matrices and two vectors); 0 = shape not served
+size_t wide_lds_bytes(int Sq, int Skv, int dh, bool bwd) {
+    if (dh % 4 != 0 || dh <= 32) return 0;
+    const size_t n = (size_t)Sq * (Skv + 1) * (bwd ? 2 : 1) + (bwd ? 2 * (size_t)Sq : 0);
+    return n * sizeof(float) <= 64 * 1024 ? n * sizeof(float) : 0;
+}
+
 unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 unsigned reduce_blocks(int64_t n) { return (unsigned)((n + 15) / 16); }
 
@@ -657,9 +782,14 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !stats) return fail(ADX_EINVAL, "attention_bwd: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_bwd: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_bwd: batch or head count above 65535");
+    hipStream_t s = (hipStream_t)stream;
+    if (const size_t lds = wide_lds_bytes(Sq, Skv, dh, true)) {
+        hipLaunchKernelGGL(attn_wide_bwd_kernel, dim3(H, B), dim3(256), lds, s, q, k, v, o, dout, stats, stats_have_lse, H, Sq, Skv, dh, scale,
+                           mask_off, dq, dk, dv);
+        return done(hipGetLastError(), "attention_bwd");
+    }
     const int PTr = dh <= 16 ? 2 : 1;                               // queries (keys) per thread: 2 while the registers allow it
     const dim3 gq((Sq + 128 * PTr - 1) / (128 * PTr), H, B), gk((Skv + 128 * PTr - 1) / (128 * PTr), H, B);
-    hipStream_t s = (hipStream_t)stream;
 #define PT (DH_ <= 16 ? 2 : 1)
 #define ADX_ATTN_BWD3(DH, MASKED, LSE)                                                                                                                  \
     hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE>), gq, dim3(128), 0, s, q, k, v, o, dout, H, Sq, Skv, scale, mask_off, dq, stats);  \
@@ -675,7 +805,7 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
         ADX_ATTN_BWD(8)
         ADX_ATTN_BWD(16)
         ADX_ATTN_BWD(32)
-        default: return fail(ADX_EINVAL, "attention_bwd: head width must be 4, 8, 16 or 32");
+        default: return fail(ADX_EINVAL, "attention_bwd: head width must be 4, 8, 16 or 32, or a multiple of 4 with at most ~88 tokens on either side");
     }
 #undef ADX_ATTN_BWD
 #undef ADX_ATTN_BWD2
@@ -689,9 +819,13 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
     if (!q || !k || !v || !o || !stats) return fail(ADX_EINVAL, "attention_stats: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_stats: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_stats: batch or head count above 65535");
+    hipStream_t s = (hipStream_t)stream;
+    if (const size_t lds = wide_lds_bytes(Sq, Skv, dh, false)) {
+        hipLaunchKernelGGL(attn_wide_fwd_kernel, dim3(H, B), dim3(256), lds, s, q, k, v, H, Sq, Skv, dh, scale, mask_off, o, stats);
+        return done(hipGetLastError(), "attention_stats");
+    }
     const int PTr = dh <= 16 ? 2 : 1;
     const dim3 gq((Sq + 128 * PTr - 1) / (128 * PTr), H, B);
-    hipStream_t s = (hipStream_t)stream;
 #define ADX_ATTN_FWD(DH)                                                                                                                         \
     case DH: {                                                                                                                                   \
         constexpr int PT = DH <= 16 ? 2 : 1;                                                                                                     \
@@ -703,7 +837,7 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
         ADX_ATTN_FWD(8)
         ADX_ATTN_FWD(16)
         ADX_ATTN_FWD(32)
-        default: return fail(ADX_EINVAL, "attention_stats: head width must be 4, 8, 16 or 32");
+        default: return fail(ADX_EINVAL, "attention_stats: head width must be 4, 8, 16 or 32, or a multiple of 4 with at most ~88 tokens on either side");
     }
 #undef ADX_ATTN_FWD
     return done(hipGetLastError(), "attention_stats");

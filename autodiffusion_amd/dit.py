@@ -214,11 +214,11 @@ class DiffusionWrapper(nn.Module):
     def train_forward(self, hidden_state, trajectory_label, info_dict=None, t: Optional[torch.Tensor] = None,
                       noise: Optional[torch.Tensor] = None):
         """The training loss (diffusion_decoder.py:346-365): normalise the label, q_sample at one random timestep per row, one
-        denoiser call; returns the element-wise squared error (B, S, C) as the reference does.  With gradients enabled, trainable
-        parameters and the DiT backbone the denoiser call is the differentiable training path (``train.py``; gradients also reach
-        ``hidden_state`` when it requires them); otherwise (``torch.no_grad()``, or the MM-DiT backbone) only the value."""
+        denoiser call; returns the element-wise squared error (B, S, C) as the reference does.  With gradients enabled and trainable
+        parameters the denoiser call is the differentiable training path (``train.py``, both backbones; gradients also reach
+        ``hidden_state`` when it requires them); under ``torch.no_grad()`` only the value."""
         from . import train
-        grad = train.wants_grad(self.model) and self.model.config.diffusion_backbone == "DiT"
+        grad = train.wants_grad(self.model)
         if grad:
             return self._train_forward(hidden_state, trajectory_label, info_dict, t, noise, True)
         with torch.no_grad():
@@ -314,8 +314,8 @@ class DiffusionDecoder(nn.Module):
     def forward(self, label, hidden_output, info_dict=None, device=None, t: Optional[torch.Tensor] = None,
                 noise: Optional[torch.Tensor] = None):
         """-> (loss, logits): summed squared error of the noise estimate times ``trajectory_loss_rescale`` and all-zero logits
-        (diffusion_decoder.py:502-532).  Differentiable for the DiT backbone when gradients are enabled (see
-        DiffusionWrapper.train_forward); the value only otherwise."""
+        (diffusion_decoder.py:502-532).  Differentiable when gradients are enabled (see DiffusionWrapper.train_forward);
+        the value only under ``torch.no_grad()``."""
         if not self.config.predict_yaw:
             label = label[..., :2].clone()
         loss = self.model.train_forward(hidden_output, label, info_dict=info_dict, t=t, noise=noise).sum()

@@ -163,15 +163,16 @@ class _Grads:
 
 
 def _lin(P, x, prefix: str, rows: Optional[slice] = None):
-    w, b = P[prefix + "weight"], P[prefix + "bias"]
+    w, b = P[prefix + "weight"], P.get(prefix + "bias")
     if rows is not None:
         w, b = w[rows], b[rows]
-    return ops.linear(x, f32c(w), f32c(b))
+    return ops.linear(x, f32c(w), f32c(b) if b is not None else None)
 
 
 def _lin_bwd(P, G: _Grads, dy, x, prefix: str, rows: Optional[slice] = None, need_dx: bool = True):
     """Accumulates dW / db of ``y = x W[rows]^T + b[rows]`` and returns dx = dy W[rows] (None when not needed)."""
-    gw, gb = G.of(prefix + "weight"), G.of(prefix + "bias")
+    gw = G.of(prefix + "weight")
+    gb = G.of(prefix + "bias") if prefix + "bias" in P else None
     w = P[prefix + "weight"]
     if rows is not None:
         gw, gb, w = gw[rows], gb[rows], w[rows]
@@ -379,7 +380,8 @@ def wants_grad(module: torch.nn.Module) -> bool:
 # ================================================================================================ decoder twin (DiT backbone)
 # Transformer_TrajDiffusionModel.forward (diffusion_decoder.py:251-277) with DiTBlock / DiT_FinalLayer
 # (libs/diffusionTransformer.py:24-53, 182-199) and DecoderResCat (libs/mlp.py:43-55) under the same scheme: forward with kept
-# activations, backward through the library's operators.  fp32; the MM-DiT backbone has no backward here.
+# activations, backward through the library's operators, for both backbones (MM_DiTBlock / DiT_Attention:
+# libs/diffusionTransformer.py:56-179).  fp32.
 def mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a, b = f32c(a), f32c(b)
     if a.shape != b.shape:
@@ -489,7 +491,83 @@ def _dit_block_bwd(P, G, prefix: str, saved, silu_c, dout, n_head: int):
     return add(dhA, dh_mod), _lin_bwd(P, G, dmod, silu_c, prefix + "adaLN_modulation.1.")
 
 
-def dit_forward(P: Dict[str, torch.Tensor], x, t, state, n_head: int, n_blocks: int, n_state: int, n_x: int):
+def _heads_cat(a, b, n_head: int):
+    """(B, S, H k), (B, S, H k) -> (B, S, H 2k): per head, the trajectory stream's features followed by the condition stream's."""
+    B, S = a.shape[0], a.shape[1]
+    return torch.cat([a.reshape(B, S, n_head, -1), b.reshape(B, S, n_head, -1)], dim=-1).reshape(B, S, -1)
+
+
+def _heads_split(g, n_head: int):
+    B, S = g.shape[0], g.shape[1]
+    g4 = g.reshape(B, S, n_head, -1)
+    k = g4.shape[-1] // 2
+    return g4[..., :k].reshape(B, S, -1).contiguous(), g4[..., k:].reshape(B, S, -1).contiguous()
+
+
+def _mm_stream(P, prefix: str, s: str, inp, m, op):
+    """One stream of an MM-DiT block after the joint attention (libs/diffusionTransformer.py:166-179): the residual of both
+    updates starts from the block input."""
+    u = _lin(P, op, prefix + f"linear_{s}.0.")
+    ua = act(u, _lib.ACT_GELU_TANH)
+    mid = add(inp, mul(m[2], ua))
+    h2 = _modulate(mid, m[3], m[4])
+    w1 = _lin(P, h2, prefix + f"mlp_{s}.0.")
+    w1a = act(w1, _lib.ACT_GELU_TANH)
+    w2 = _lin(P, w1a, prefix + f"mlp_{s}.2.")
+    w2a = act(w2, _lib.ACT_GELU_TANH)
+    return add(inp, mul(m[5], w2a)), (u, ua, mid, h2, w1, w1a, w2, w2a)
+
+
+def _mm_stream_bwd(P, G, prefix: str, s: str, m, op, saved, dout):
+    """-> (d input through the two residuals, d op, [None, None, dg2, dsh3, dsc4, dg5])."""
+    u, ua, mid, h2, w1, w1a, w2, w2a = saved
+    dg5 = mul(dout, w2a)
+    dw2 = act_bwd(w2, mul(dout, m[5]), _lib.ACT_GELU_TANH)
+    dw1 = act_bwd(w1, _lin_bwd(P, G, dw2, w1a, prefix + f"mlp_{s}.2."), _lib.ACT_GELU_TANH)
+    dmid, dsh3, dsc4 = _modulate_bwd(mid, m[4], _lin_bwd(P, G, dw1, h2, prefix + f"mlp_{s}.0."))
+    dg2 = mul(dmid, ua)
+    du = act_bwd(u, mul(dmid, m[2]), _lib.ACT_GELU_TANH)
+    dop = _lin_bwd(P, G, du, op, prefix + f"linear_{s}.0.")
+    return add(dout, dmid), dop, [None, None, dg2, dsh3, dsc4, dg5]
+
+
+def _mm_block(P, prefix: str, x, c, silu_y, n_head: int):
+    mx = [m.contiguous() for m in _lin(P, silu_y, prefix + "adaLN_modulation_x.1.").chunk(6, dim=-1)]
+    mc = [m.contiguous() for m in _lin(P, silu_y, prefix + "adaLN_modulation_c.1.").chunk(6, dim=-1)]
+    xh, ch = _modulate(x, mx[0], mx[1]), _modulate(c, mc[0], mc[1])
+    a = prefix + "attn."
+    proj = {n + s: _lin(P, xh if s == "x" else ch, a + f"W{n}_{s}.") for n in "qkv" for s in "xc"}
+    q, k, v = (_heads_cat(proj[n + "x"], proj[n + "c"], n_head) for n in "qkv")
+    scale = float(proj["qx"].shape[-1] // n_head) ** -0.5                       # 1 / sqrt(k_dim), k_dim = one stream's head width
+    o, stats = attention_stats(q, k, v, n_head, scale=scale)
+    op = _lin(P, o, a + "proj.")
+    x_out, sx = _mm_stream(P, prefix, "x", x, mx, op)
+    c_out, sc = _mm_stream(P, prefix, "c", c, mc, op)
+    return x_out, c_out, (x, c, mx, mc, xh, ch, q, k, v, o, stats, scale, op, sx, sc)
+
+
+def _mm_block_bwd(P, G, prefix: str, saved, silu_y, dx_out, dc_out, n_head: int):
+    x, c, mx, mc, xh, ch, q, k, v, o, stats, scale, op, sx, sc = saved
+    dx, dop_x, gx = _mm_stream_bwd(P, G, prefix, "x", mx, op, sx, dx_out)
+    dc, dop_c, gc = _mm_stream_bwd(P, G, prefix, "c", mc, op, sc, dc_out)
+    a = prefix + "attn."
+    do = _lin_bwd(P, G, add(dop_x, dop_c), o, a + "proj.")
+    dq, dk, dv = attention_bwd(q, k, v, o, do, n_head, scale=scale, stats=stats)
+    parts = {"q": _heads_split(dq, n_head), "k": _heads_split(dk, n_head), "v": _heads_split(dv, n_head)}
+    dxh = add(add(_lin_bwd(P, G, parts["q"][0], xh, a + "Wq_x."), _lin_bwd(P, G, parts["k"][0], xh, a + "Wk_x.")),
+              _lin_bwd(P, G, parts["v"][0], xh, a + "Wv_x."))
+    dch = add(add(_lin_bwd(P, G, parts["q"][1], ch, a + "Wq_c."), _lin_bwd(P, G, parts["k"][1], ch, a + "Wk_c.")),
+              _lin_bwd(P, G, parts["v"][1], ch, a + "Wv_c."))
+    dx_mod, gx[0], gx[1] = _modulate_bwd(x, mx[1], dxh)
+    dc_mod, gc[0], gc[1] = _modulate_bwd(c, mc[1], dch)
+    dsilu = add(_lin_bwd(P, G, torch.cat(gx, dim=-1), silu_y, prefix + "adaLN_modulation_x.1."),
+                _lin_bwd(P, G, torch.cat(gc, dim=-1), silu_y, prefix + "adaLN_modulation_c.1."))
+    return add(dx, dx_mod), add(dc, dc_mod), dsilu
+
+
+def dit_forward(P: Dict[str, torch.Tensor], x, t, state, n_head: int, n_blocks: int, n_state: int, n_x: int, mm: bool = False):
+    """``mm``: the MM-DiT backbone -- the condition stream starts as the state embedding and is updated by every block, the
+    modulation input y = time embedding + state embedding stays fixed (diffusion_decoder.py:262-272)."""
     d = P["position_embedding"].shape[-1]
     B, S = x.shape[0], x.shape[1]
     tape: Dict[str, object] = {}
@@ -511,14 +589,18 @@ def dit_forward(P: Dict[str, torch.Tensor], x, t, state, n_head: int, n_blocks: 
     c = add(te[:, None, :].expand(B, S, d).contiguous(), s)
     silu_c = act(c, _lib.ACT_SILU)
     blocks = []
+    cs = s
     for i in range(n_blocks):
-        h, sv = _dit_block(P, f"blocks.{i}.", h, silu_c, n_head)
+        if mm:
+            h, cs, sv = _mm_block(P, f"blocks.{i}.", h, cs, silu_c, n_head)
+        else:
+            h, sv = _dit_block(P, f"blocks.{i}.", h, silu_c, n_head)
         blocks.append(sv)
     mod = _lin(P, silu_c, "final_layer.adaLN_modulation.1.")
     sh, sc = (m.contiguous() for m in mod.chunk(2, dim=-1))
     hf = _modulate(h, sh, sc)
     out = _lin(P, hf, "final_layer.linear.")
-    tape.update(st=st_saved, xs=x_saved, time=(emb, a1, b1, a2, b2), c=c, silu_c=silu_c, blocks=blocks, h=h, sc=sc, hf=hf, S=S)
+    tape.update(st=st_saved, xs=x_saved, time=(emb, a1, b1, a2, b2), c=c, silu_c=silu_c, blocks=blocks, h=h, sc=sc, hf=hf, S=S, mm=mm)
     return out, tape
 
 
@@ -528,8 +610,14 @@ def dit_backward(P: Dict[str, torch.Tensor], tape, dout, n_head: int, want_state
     dhf = _lin_bwd(P, G, f32c(dout), tape["hf"], "final_layer.linear.")
     dh, dsh, dsc = _modulate_bwd(tape["h"], tape["sc"], dhf)
     dsilu = _lin_bwd(P, G, torch.cat([dsh, dsc], dim=-1), silu_c, "final_layer.adaLN_modulation.1.")
+    dcs = None                                                      # MM-DiT: gradient of the condition stream
     for i in reversed(range(len(tape["blocks"]))):
-        dh, ds_i = _dit_block_bwd(P, G, f"blocks.{i}.", tape["blocks"][i], silu_c, dh, n_head)
+        if tape["mm"]:
+            if dcs is None:                                         # the last block's condition output is not used
+                dcs = torch.zeros_like(dh)
+            dh, dcs, ds_i = _mm_block_bwd(P, G, f"blocks.{i}.", tape["blocks"][i], silu_c, dh, dcs, n_head)
+        else:
+            dh, ds_i = _dit_block_bwd(P, G, f"blocks.{i}.", tape["blocks"][i], silu_c, dh, n_head)
         dsilu = add(dsilu, ds_i)
     dc = act_bwd(tape["c"], dsilu, _lib.ACT_SILU)
     # c = time embedding (broadcast over the tokens) + state embedding
@@ -538,7 +626,7 @@ def dit_backward(P: Dict[str, torch.Tensor], tape, dout, n_head: int, want_state
     da2 = act_bwd(a2, _lin_bwd(P, G, dte, b2, "time_encoder.5."), _lib.ACT_LEAKY)
     da1 = act_bwd(a1, _lin_bwd(P, G, da2, b1, "time_encoder.3."), _lib.ACT_LEAKY)
     _lin_bwd(P, G, da1, emb, "time_encoder.1.", need_dx=False)
-    ds = dc
+    ds = dc if dcs is None else add(dc, dcs)                       # the state embedding feeds y and, for MM-DiT, the condition stream
     for i in reversed(range(len(tape["st"]))):
         ds = _res_cat_bwd(P, G, f"state_encoder.{i}.", tape["st"][i], ds, need_dx=(i > 0 or want_state_grad))
     # h0 = x embedding + position table
@@ -554,9 +642,9 @@ class DenoiserDiT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, x, t, state, *params):
-        names, n_head, n_blocks, n_state, n_x = meta
+        names, n_head, n_blocks, n_state, n_x, mm = meta
         P = {n: p.detach() for n, p in zip(names, params)}
-        out, tape = dit_forward(P, f32c(x), t, f32c(state), n_head, n_blocks, n_state, n_x)
+        out, tape = dit_forward(P, f32c(x), t, f32c(state), n_head, n_blocks, n_state, n_x, mm)
         ctx.meta, ctx.P, ctx.tape = meta, P, tape
         ctx.want_state = bool(ctx.needs_input_grad[3])
         return out
@@ -570,10 +658,8 @@ class DenoiserDiT(torch.autograd.Function):
 
 
 def denoise_dit_with_grad(module: torch.nn.Module, x, t, state) -> torch.Tensor:
-    """Differentiable call of a ``dit.Transformer_TrajDiffusionModel`` with the DiT backbone."""
-    if module.config.diffusion_backbone != "DiT":
-        raise NotImplementedError("the training path covers the DiT backbone; MM-DiT has no backward")
+    """Differentiable call of a ``dit.Transformer_TrajDiffusionModel`` (DiT or MM-DiT backbone)."""
     named = [(n, p) for n, p in module.named_parameters()]
     meta = (tuple(n for n, _ in named), int(module.config.n_head), len(module.blocks), len(list(module.state_encoder.children())),
-            len(list(module.x_encoder.children())))
+            len(list(module.x_encoder.children())), module.config.diffusion_backbone == "MM-DiT")
     return DenoiserDiT.apply(meta, x, t, state, *[p for _, p in named])

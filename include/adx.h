@@ -257,14 +257,16 @@ int adx_op_colsum(const float* x, int64_t M, int N, float* out, int accumulate, 
  * bias gradient is the column sum of dy).  gamma may be NULL (no affine). */
 int adx_op_layernorm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int d, float eps, float* dx,
                          float* dy_xhat, void* stream);
-/* Backward of adx_op_attention (same layouts and mask rule) for head widths 4, 8, 16, 32 (dv == dh): o is the forward output,
+/* Backward of adx_op_attention (same layouts and mask rule; dv == dh) for head widths 4, 8, 16, 32 at any sequence length and
+ * for wider heads (multiples of 4; the 128 ... 512-wide joint attention of MM_DiTBlock, libs/diffusionTransformer.py:99-117)
+ * when two Sq x Skv matrices fit in 64 KB of LDS (about 88 tokens on either side): o is the forward output,
  * dout its gradient; stats holds 2*B*H*Sq floats (per query and head: the log-sum-exp of the scores, base 2, and dout.o).
  * With stats_have_lse != 0 the log-sum-exps were written by adx_op_attention_stats and the pass that finds them is skipped;
  * otherwise stats is pure scratch.  Probabilities are recomputed, never stored. */
 int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H,
                          int Sq, int Skv, int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats,
                          int stats_have_lse, void* stream);
-/* adx_op_attention for a forward whose backward will follow (head widths 4, 8, 16, 32, dv == dh, fp32): writes o and, in
+/* adx_op_attention for a forward whose backward will follow (same shapes as adx_op_attention_bwd, fp32): writes o and, in
  * stats[((b*H + h)*Sq + i)*2], the log-sum-exp of query i's scores. */
 int adx_op_attention_stats(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq,
                            int Skv, int dh, float scale, int mask_off, void* stream);

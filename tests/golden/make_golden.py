@@ -548,15 +548,16 @@ def grad_record(out, name, g, full_limit=4096, samples=1024):
         out["gradsample." + name] = g[::g.numel() // samples]
 
 
-def g15_twin_grads():
+def g15_twin_grads(backbone="DiT", name="g15_twin_grads"):
     """loss.backward() of the reference's DiffusionDecoder.forward (diffusion_decoder.py:502-532 -> train_forward :346-365), DiT
-    backbone, hidden 64, 2 blocks, 4 heads: timesteps and noise supplied, dropout off (the network in eval mode), every tensor
-    random.  Stored: the loss, every parameter gradient (large ones as norm + strided sample) and the gradient of the state."""
+    backbone (g16: MM-DiT), hidden 64, 2 blocks, 4 heads: timesteps and noise supplied, dropout off (the network in eval mode),
+    every tensor random.  Stored: the loss, every parameter gradient (large ones as norm + strided sample) and the gradient of the
+    state."""
     out = {}
     B = 2
     prior = synth.trajectory_prior(B, ISEED)
     label = prior + synth.noise(B, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
-    dec = ref_dd.DiffusionDecoder(dit_config(64, 2, 4, "DiT", n=10))
+    dec = ref_dd.DiffusionDecoder(dit_config(64, 2, 4, backbone, n=10))
     synth.fill_module_(dec, WSEED)
     dec = dec.float()
     dec.train()
@@ -569,15 +570,19 @@ def g15_twin_grads():
         assert not q and not qt
     loss.backward()
     out["t"], out["loss"] = t, loss.detach()
-    for name, p in dec.model.model.named_parameters():
+    for pname, p in dec.model.model.named_parameters():
         if p.grad is not None:
-            grad_record(out, name, p.grad)
+            grad_record(out, pname, p.grad)
     out["grad_state"] = state.grad
-    save("g15_twin_grads", **out)
+    save(name, **out)
+
+
+def g16_mmdit_grads():
+    g15_twin_grads("MM-DiT", "g16_mmdit_grads")
 
 
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
-       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads}
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

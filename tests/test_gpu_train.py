@@ -102,7 +102,8 @@ def test_op_layernorm_bwd(dev, rows, d):
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,dh,mask_off", [(2, 8, 809, 809, 4, -1), (3, 8, 10, 10, 4, 0), (3, 8, 10, 809, 4, 1), (2, 8, 80, 949, 4, 1),
-                                                   (1, 2, 130, 257, 8, -1), (2, 4, 33, 33, 16, 0), (2, 8, 80, 80, 32, -1), (1, 3, 200, 140, 32, 2)])
+                                                   (1, 2, 130, 257, 8, -1), (2, 4, 33, 33, 16, 0), (2, 8, 80, 80, 32, -1), (1, 3, 200, 140, 32, 2),
+                                                   (2, 4, 80, 80, 128, -1), (1, 2, 80, 80, 512, -1), (2, 3, 37, 61, 64, 1)])
 def test_op_attention_bwd(dev, B, H, Sq, Skv, dh, mask_off):
     from autodiffusion_amd import ops, train
     from oracle import nets
@@ -332,12 +333,13 @@ def check_grad_fixture(g, grads, tol):
     return seen
 
 
-def test_decoder_twin_gradients_match_the_reference(dev, golden):
-    """loss.backward() through DiffusionDecoder.forward (DiT backbone, hidden 64, 2 blocks, 4 heads) on the HIP training path
+@pytest.mark.parametrize("backbone,fixture", [("DiT", "g15_twin_grads"), ("MM-DiT", "g16_mmdit_grads")])
+def test_decoder_twin_gradients_match_the_reference(dev, golden, backbone, fixture):
+    """loss.backward() through DiffusionDecoder.forward (hidden 64, 2 blocks, 4 heads, both backbones) on the HIP training path
     against the gradients of the reference's own backward(): every parameter tensor and the backbone hidden state."""
     from autodiffusion_amd import dit, synth
-    g = golden("g15_twin_grads")
-    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "DiT", diffusion_timesteps=10))
+    g = golden(fixture)
+    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, backbone, diffusion_timesteps=10))
     synth.fill_module_(dec, WSEED)
     dec = dec.to(dev).train()
     state = synth.hidden_state(2, 64, ISEED).to(dev).requires_grad_(True)
@@ -348,12 +350,13 @@ def test_decoder_twin_gradients_match_the_reference(dev, golden):
     loss.backward()
     grads = {n: p.grad for n, p in dec.model.model.named_parameters() if p.grad is not None}
     n = check_grad_fixture(g, grads, GATE)
-    assert n == len(grads) and n > 60
+    assert n > 60
+    in_fixture = {k.partition(".")[2] for k in g if k.startswith(("grad.", "gradnorm."))}
+    for name, gr in grads.items():          # parameters the loss does not depend on (the last MM-DiT block's condition-stream
+        if name not in in_fixture:          # output is unused): the reference leaves .grad unset, here it is zero
+            assert not gr.any(), name
     assert l2_rel(state.grad, g["grad_state"]) < GATE
     with torch.no_grad():
         val, _ = dec(label, state, t=T(g["t"]).to(dev), noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
     assert not val.requires_grad
     np.testing.assert_allclose(float(val), float(g["loss"]), rtol=1e-3)
-    # the MM-DiT backbone has no backward: its loss is a value
-    mm = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "MM-DiT", diffusion_timesteps=10)).to(dev).train()
-    assert not mm(label, state.detach())[0].requires_grad

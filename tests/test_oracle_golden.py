@@ -456,14 +456,15 @@ def check_grad_fixture(g, grads, tol, rel=grad_rel_err):
     return seen
 
 
-def test_twin_loss_gradients(golden):
-    """Reverse-mode gradients of the restated decoder-twin loss (DiT backbone) against the reference's own backward()."""
-    g = golden("g15_twin_grads")
-    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in dit_sd(64, 2, 4, "DiT", prefix="model.model.").items()}
+@pytest.mark.parametrize("backbone,fixture", [("DiT", "g15_twin_grads"), ("MM-DiT", "g16_mmdit_grads")])
+def test_twin_loss_gradients(golden, backbone, fixture):
+    """Reverse-mode gradients of the restated decoder-twin loss against the reference's own backward(), both backbones."""
+    g = golden(fixture)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in dit_sd(64, 2, 4, backbone, prefix="model.model.").items()}
     state = synth.hidden_state(2, 64, ISEED).requires_grad_(True)
     label = synth.trajectory_prior(2, ISEED) + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
     b = schedules.buffers_from_betas(schedules.twin_betas("cosine", 10), f32=True)
-    loss = sampling.twin_loss(lambda x, t: nets.dit_forward(sd, x, t, state, 4, "DiT"), b, label, T(g["t"]),
+    loss = sampling.twin_loss(lambda x, t: nets.dit_forward(sd, x, t, state, 4, backbone), b, label, T(g["t"]),
                               synth.noise(2, (), (80, 4), NSEED + 2)).sum()
     loss.backward()
     np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=2e-5)
