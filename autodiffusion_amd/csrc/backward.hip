@@ -528,16 +528,74 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
 // The joint attention of the MM-DiT blocks (80 tokens, head width 2 d = 128 ... 512; libs/diffusionTransformer.py:99-117): one
 // workgroup per (item, head), the Sq x Skv probability matrix lives in LDS (and in the backward a second matrix for dS), the
 // head dimension is walked with 16-byte loads.  Scores in base 2: the statistics are those of attn_fwd_stats_kernel.
-__device__ __forceinline__ float dot_rows(const float* a, const float* b, int DH) {
-    float s = 0.f;
-    for (int e = 0; e < DH; e += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(a + e), y = *reinterpret_cast<const float4*>(b + e);
-        s = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, fmaf(x.w, y.w, s))));
+// out[i][j] = sum_e A[i][e] B[j][e] for i < Sa, j < Sb (rows of stride lda / ldb in global memory, out in LDS with row stride ldo).
+// A wave owns a 4 x 4 block of pairs and its lanes split the head dimension, so every load is a coalesced 256-byte piece of a
+// row and is used four times; the sixteen lane-partial sums are combined with butterfly exchanges.
+constexpr int kWideThreads = 1024;           // 16 waves per workgroup, four per SIMD: the products below are chains of dependent
+constexpr int kWideWaves = kWideThreads / 64;   // global loads, and one workgroup per (item, head) leaves a CU nothing else to run
+
+__device__ __forceinline__ void pair_dots(const float* A, int lda, const float* B, int ldb, int Sa, int Sb, int DH, float* out, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb = (Sb + 3) >> 2, n_tiles = ((Sa + 3) >> 2) * tb;
+    for (int tile = wave; tile < n_tiles; tile += kWideWaves) {
+        const int i0 = (tile / tb) * 4, j0 = (tile % tb) * 4;
+        float acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc[u][w] = 0.f;
+        for (int e = lane; e < DH; e += 64) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = A[(int64_t)min(i0 + u, Sa - 1) * lda + e];
+                b[u] = B[(int64_t)min(j0 + u, Sb - 1) * ldb + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc[u][w] = fmaf(a[u], b[w], acc[u][w]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                float v = acc[u][w];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0 && i0 + u < Sa && j0 + w < Sb) out[(i0 + u) * ldo + j0 + w] = v;
+            }
     }
-    return s;
 }
 
-__global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const float* q, const float* k, const float* v, int H, int Sq, int Skv, int DH,
+// out[i][e] = scale * sum_j M(i, j) V[j][e] for i < Sa, e < DH, with M(i, j) = TRANS ? Mat[j][i] : Mat[i][j] read from LDS
+// (broadcast) and V rows in global memory.  A thread owns one column e and eight rows i: a value of V is loaded once per
+// eight products, adjacent threads read adjacent columns.
+template <bool TRANS>
+__device__ __forceinline__ void matrix_times_rows(const float* Mat, int ldm, int Sa, int Sb, const float* V, int ldv, int DH, float scale,
+                                                  float* out, int ldo) {
+    const int n_groups = (Sa + 7) >> 3;
+    for (int idx = threadIdx.x; idx < n_groups * DH; idx += kWideThreads) {
+        const int e = idx % DH, i0 = (idx / DH) * 8;
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < Sb; ++j) {
+            const float vv = V[(int64_t)j * ldv + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, Sa - 1);
+                acc[u] = fmaf(TRANS ? Mat[j * ldm + i] : Mat[i * ldm + j], vv, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u < Sa) out[(int64_t)(i0 + u) * ldo + e] = acc[u] * scale;
+    }
+}
+
+__global__ __launch_bounds__(kWideThreads) void attn_wide_fwd_kernel(const float* q, const float* k, const float* v, int H, int Sq, int Skv, int DH,
                                                              float scale, int mask_off, float* o, float* stats) {
     extern __shared__ float wide_lds[];
     float* P = wide_lds;                                            // [Sq][Skv + 1]
@@ -545,20 +603,22 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const float* q, cons
     const float* qb = q + (int64_t)b * Sq * ld + h * DH;
     const float* kb = k + (int64_t)b * Skv * ld + h * DH;
     const float* vb = v + (int64_t)b * Skv * ld + h * DH;
-    for (int idx = threadIdx.x; idx < Sq * Skv; idx += 256) {
-        const int i = idx / Skv, j = idx % Skv;
-        const bool vis = mask_off < 0 || j <= i + mask_off;
-        P[i * ldp + j] = vis ? dot_rows(qb + (int64_t)i * ld, kb + (int64_t)j * ld, DH) * (scale * kLog2e) : -INFINITY;
-    }
+    pair_dots(qb, ld, kb, ld, Sq, Skv, DH, P, ldp);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < Sq; i += 4) {
+    for (int i = wave; i < Sq; i += kWideWaves) {
+        const int last = mask_off < 0 ? Skv - 1 : min(Skv - 1, i + mask_off);
         float m = -INFINITY;
-        for (int j = lane; j < Skv; j += 64) m = fmaxf(m, P[i * ldp + j]);
+        for (int j = lane; j <= last; j += 64) m = fmaxf(m, P[i * ldp + j]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        m *= scale * kLog2e;
         float l = 0.f;
-        for (int j = lane; j < Skv; j += 64) { const float p = exp2_raw(P[i * ldp + j] - m); P[i * ldp + j] = p; l += p; }
+        for (int j = lane; j < Skv; j += 64) {
+            const float p = j <= last ? exp2_raw(fmaf(P[i * ldp + j], scale * kLog2e, -m)) : 0.f;
+            P[i * ldp + j] = p;
+            l += p;
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
         const float inv = 1.0f / l;
@@ -566,23 +626,16 @@ __global__ __launch_bounds__(256) void attn_wide_fwd_kernel(const float* q, cons
         if (lane == 0) stats[(((int64_t)b * H + h) * Sq + i) * 2] = m + log2f(l);
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < Sq * DH; idx += 256) {
-        const int i = idx / DH, e = idx % DH;
-        float acc = 0.f;
-        for (int j = 0; j < Skv; ++j) acc = fmaf(P[i * ldp + j], vb[(int64_t)j * ld + e], acc);
-        o[((int64_t)b * Sq + i) * ld + h * DH + e] = acc;
-    }
+    matrix_times_rows<false>(P, ldp, Sq, Skv, vb, ld, DH, 1.0f, o + (int64_t)b * Sq * ld + h * DH, ld);
 }
 
-__global__ __launch_bounds__(256) void attn_wide_bwd_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
+__global__ __launch_bounds__(kWideThreads) void attn_wide_bwd_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
                                                              float* stats, int have_lse, int H, int Sq, int Skv, int DH, float scale, int mask_off,
                                                              float* dq, float* dk, float* dv) {
     extern __shared__ float wide_lds[];
     const int b = blockIdx.y, h = blockIdx.x, ld = H * DH, ldp = Skv + 1;
     float* P = wide_lds;                                            // [Sq][Skv + 1]
     float* dS = P + Sq * ldp;                                       // [Sq][Skv + 1]
-    float* Dv = dS + Sq * ldp;                                      // [Sq]: dout . o
-    float* Ls = Dv + Sq;                                            // [Sq]: log-sum-exp
     const float* qb = q + (int64_t)b * Sq * ld + h * DH;
     const float* kb = k + (int64_t)b * Skv * ld + h * DH;
     const float* vb = v + (int64_t)b * Skv * ld + h * DH;
@@ -590,24 +643,22 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_kernel(const float* q, cons
     const float* gb = dout + (int64_t)b * Sq * ld + h * DH;
     float* st = stats + ((int64_t)b * H + h) * Sq * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int idx = threadIdx.x; idx < Sq * Skv; idx += 256) {
-        const int i = idx / Skv, j = idx % Skv;
-        const bool vis = mask_off < 0 || j <= i + mask_off;
-        P[i * ldp + j] = vis ? dot_rows(qb + (int64_t)i * ld, kb + (int64_t)j * ld, DH) * (scale * kLog2e) : -INFINITY;
-        dS[i * ldp + j] = dot_rows(gb + (int64_t)i * ld, vb + (int64_t)j * ld, DH);
-    }
+    pair_dots(qb, ld, kb, ld, Sq, Skv, DH, P, ldp);                 // raw scores
+    pair_dots(gb, ld, vb, ld, Sq, Skv, DH, dS, ldp);                // dP = dout . v
     __syncthreads();
-    for (int i = wave; i < Sq; i += 4) {
+    for (int i = wave; i < Sq; i += kWideWaves) {
+        const int last = mask_off < 0 ? Skv - 1 : min(Skv - 1, i + mask_off);
         float lse;
         if (have_lse) {
             lse = st[i * 2];
         } else {
             float m = -INFINITY;
-            for (int j = lane; j < Skv; j += 64) m = fmaxf(m, P[i * ldp + j]);
+            for (int j = lane; j <= last; j += 64) m = fmaxf(m, P[i * ldp + j]);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            m *= scale * kLog2e;
             float l = 0.f;
-            for (int j = lane; j < Skv; j += 64) l += exp2_raw(P[i * ldp + j] - m);
+            for (int j = lane; j <= last; j += 64) l += exp2_raw(fmaf(P[i * ldp + j], scale * kLog2e, -m));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
             lse = m + log2f(l);
@@ -617,35 +668,22 @@ __global__ __launch_bounds__(256) void attn_wide_bwd_kernel(const float* q, cons
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
         for (int j = lane; j < Skv; j += 64) {
-            const float p = exp2_raw(P[i * ldp + j] - lse);
+            const float p = j <= last ? exp2_raw(fmaf(P[i * ldp + j], scale * kLog2e, -lse)) : 0.f;
             P[i * ldp + j] = p;
             dS[i * ldp + j] = p * (dS[i * ldp + j] - d);
         }
         if (lane == 0) { st[i * 2] = lse; st[i * 2 + 1] = d; }
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < Sq * DH; idx += 256) {
-        const int i = idx / DH, e = idx % DH;
-        float acc = 0.f;
-        for (int j = 0; j < Skv; ++j) acc = fmaf(dS[i * ldp + j], kb[(int64_t)j * ld + e], acc);
-        dq[((int64_t)b * Sq + i) * ld + h * DH + e] = acc * scale;
-    }
-    for (int idx = threadIdx.x; idx < Skv * DH; idx += 256) {
-        const int j = idx / DH, e = idx % DH;
-        float ak = 0.f, av = 0.f;
-        for (int i = 0; i < Sq; ++i) {
-            ak = fmaf(dS[i * ldp + j], qb[(int64_t)i * ld + e], ak);
-            av = fmaf(P[i * ldp + j], gb[(int64_t)i * ld + e], av);
-        }
-        dk[((int64_t)b * Skv + j) * ld + h * DH + e] = ak * scale;
-        dv[((int64_t)b * Skv + j) * ld + h * DH + e] = av;
-    }
+    matrix_times_rows<false>(dS, ldp, Sq, Skv, kb, ld, DH, scale, dq + (int64_t)b * Sq * ld + h * DH, ld);      // dq = scale dS k
+    matrix_times_rows<true>(dS, ldp, Skv, Sq, qb, ld, DH, scale, dk + (int64_t)b * Skv * ld + h * DH, ld);      // dk = scale dS^T q
+    matrix_times_rows<true>(P, ldp, Skv, Sq, gb, ld, DH, 1.0f, dv + (int64_t)b * Skv * ld + h * DH, ld);        // dv = P^T dout
 }
 
 // bytes of LDS the wide-head kernels need (forward: one matrix; backward: two matrices and two vectors); 0 = shape not served
 size_t wide_lds_bytes(int Sq, int Skv, int dh, bool bwd) {
     if (dh % 4 != 0 || dh <= 32) return 0;
-    const size_t n = (size_t)Sq * (Skv + 1) * (bwd ? 2 : 1) + (bwd ? 2 * (size_t)Sq : 0);
+    const size_t n = (size_t)Sq * (Skv + 1) * (bwd ? 2 : 1);
     return n * sizeof(float) <= 64 * 1024 ? n * sizeof(float) : 0;
 }
 
@@ -784,7 +822,7 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_bwd: batch or head count above 65535");
     hipStream_t s = (hipStream_t)stream;
     if (const size_t lds = wide_lds_bytes(Sq, Skv, dh, true)) {
-        hipLaunchKernelGGL(attn_wide_bwd_kernel, dim3(H, B), dim3(256), lds, s, q, k, v, o, dout, stats, stats_have_lse, H, Sq, Skv, dh, scale,
+        hipLaunchKernelGGL(attn_wide_bwd_kernel, dim3(H, B), dim3(kWideThreads), lds, s, q, k, v, o, dout, stats, stats_have_lse, H, Sq, Skv, dh, scale,
                            mask_off, dq, dk, dv);
         return done(hipGetLastError(), "attention_bwd");
     }
@@ -821,7 +859,7 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_stats: batch or head count above 65535");
     hipStream_t s = (hipStream_t)stream;
     if (const size_t lds = wide_lds_bytes(Sq, Skv, dh, false)) {
-        hipLaunchKernelGGL(attn_wide_fwd_kernel, dim3(H, B), dim3(256), lds, s, q, k, v, H, Sq, Skv, dh, scale, mask_off, o, stats);
+        hipLaunchKernelGGL(attn_wide_fwd_kernel, dim3(H, B), dim3(kWideThreads), lds, s, q, k, v, H, Sq, Skv, dh, scale, mask_off, o, stats);
         return done(hipGetLastError(), "attention_stats");
     }
     const int PTr = dh <= 16 ? 2 : 1;

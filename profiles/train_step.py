@@ -70,11 +70,13 @@ def main():
             line["cpu_autograd"] = {"ms_per_chunk": round(dc * 1e3, 1), "samples_per_s": round(B / (dc * (80 // fs)), 2),
                                     "threads": torch.get_num_threads(), "sample": "1 chunk forward + backward of the fp32 oracle, whole step = chunks x that"}
         print(json.dumps(line), flush=True)
-    if not args.only or args.only == "dit256":
-        # decoder twin, DiT backbone as ldr_diffusion.yaml sizes it (hidden 256, 4 blocks, 8 heads), the reference's debug batch of 32
+    for tag, backbone in (("dit256", "DiT"), ("mmdit256", "MM-DiT")):
+        if args.only and args.only != tag:
+            continue
+        # decoder twin as ldr_diffusion.yaml sizes it (hidden 256, 4 blocks, 8 heads), the reference's debug batch of 32
         from autodiffusion_amd import dit
         Bd = min(B, 32)
-        dec = dit.DiffusionDecoder(dit.dit_config(256, 4, 8, "DiT", diffusion_timesteps=10))
+        dec = dit.DiffusionDecoder(dit.dit_config(256, 4, 8, backbone, diffusion_timesteps=10))
         with torch.no_grad():
             for p in dec.parameters():
                 p.normal_(0.0, 0.02)
@@ -98,7 +100,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         assert bool(torch.isfinite(loss.detach()))
-        print(json.dumps({"workload": f"DiT decoder twin training step, hidden 256, 4 blocks, 8 heads, B={Bd}, fp32",
+        print(json.dumps({"workload": f"{backbone} decoder twin training step, hidden 256, 4 blocks, 8 heads, B={Bd}, fp32",
                           "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(Bd / dt, 1)}), flush=True)
 
 
