@@ -340,6 +340,8 @@ class DenoiserA(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         names, n_head = ctx.meta[0], ctx.meta[1]
+        if ctx.tape is None:
+            raise RuntimeError("the kept activations were released by the first backward: call forward again (retain_graph is not supported)")
         grads, d_tr = denoiser_backward(ctx.P, ctx.tape, dout.contiguous(), n_head, ctx.want_tr)
         ctx.tape = None
         return (None, None, None, None, d_tr, None) + tuple(grads.get(n) for n in names)
@@ -652,6 +654,8 @@ class DenoiserDiT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         names, n_head = ctx.meta[0], ctx.meta[1]
+        if ctx.tape is None:
+            raise RuntimeError("the kept activations were released by the first backward: call forward again (retain_graph is not supported)")
         grads, d_state = dit_backward(ctx.P, ctx.tape, dout.contiguous(), n_head, ctx.want_state)
         ctx.tape = None
         return (None, None, None, d_state) + tuple(grads.get(n) for n in names)
