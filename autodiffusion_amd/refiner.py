@@ -409,7 +409,8 @@ class DiffusionAugmentation(nn.Module):
         return {"traj_logits": traj}
 
     def forward(self, return_dict=None, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
-        """The evaluation-time value of the training objective (DiffusionAugmentation.py:75-135), forward only: per chunk
+        """The training objective (DiffusionAugmentation.py:75-135) -- its value under ``torch.no_grad()`` (what evaluation
+        reports), a differentiable loss when gradients are enabled (one batched pass over all chunks, ``train.py``): per chunk
         one diffusion loss of the label chunk (label minus prior with ``residual``) conditioned on the prior chunk and on the
         previous chunk's ``prediction`` -- which the reference's refiner returns as zeros, so chunks after the first see a
         zero transition.  ``t`` (n_chunks, B) and ``noise`` (n_chunks, B, fs, 4) fix the random draws.
