@@ -259,6 +259,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
+// Workgroup -> (item, head, block of queries / keys) with every workgroup of an item on ONE XCD.  Heads are interleaved in
+// memory (a 128-byte line of a row holds all eight 4-wide heads), so the workgroups of an item's heads read the same lines;
+// the hardware deals consecutive workgroup ids round-robin over the eight XCDs, each with its own L2, and with the natural
+// (block, head, item) order an item's lines were fetched from HBM by up to eight L2s (counters: 17 x the algorithmic bytes).
+// Ids congruent modulo 8 share an XCD, so item = 8 * (slot / per_item) + id % 8: the grid is padded to a multiple of 8 items.
+struct AttnBlock { int b, h, x; bool ok; };
+__device__ __forceinline__ AttnBlock attn_block(int B, int H, int nx) {
+    const int per_item = H * nx, id = blockIdx.x, slot = id >> 3, w = slot % per_item;
+    AttnBlock r;
+    r.b = (slot / per_item) * 8 + (id & 7);
+    r.h = w / nx;
+    r.x = w % nx;
+    r.ok = r.b < B;
+    return r;
+}
+unsigned attn_grid(int B, int H, int nx) { return (unsigned)(((B + 7) / 8) * 8 * H * nx); }
+
+
 // q[B][Sq][H*DH], k / v[B][Skv][H*DH], o / dout[B][Sq][H*DH]; key j is visible to query i iff mask_off < 0 or j <= i + mask_off.
 // Head widths this small fit no matrix-core shape (the f32 matrix rate equals the vector rate on this part, and bf16 products
 // on split operands would waste 7/8 of a tile on the zeros of a block-diagonal head layout), so both passes are vector code.
@@ -273,9 +291,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
 // and the weights are the probabilities themselves.
 template <int DH, int PT, bool MASKED, bool HAVE_LSE>
 __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
-                                                              int H, int Sq, int Skv, float scale, int mask_off, float* dq, float* stats) {
+                                                              int B, int nx, int H, int Sq, int Skv, float scale, int mask_off, float* dq, float* stats) {
     __shared__ float ks[128][DH], vs[128][DH];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const AttnBlock blk = attn_block(B, H, nx);
+    if (!blk.ok) return;
+    const int b = blk.b, h = blk.h, bx = blk.x;
     const int ld = H * DH;
     int iq[PT], last[PT];
     bool valid[PT];
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
     int last_all = 0;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-        iq[u] = blockIdx.x * (128 * PT) + 128 * u + threadIdx.x;
+        iq[u] = bx * (128 * PT) + 128 * u + threadIdx.x;
         valid[u] = iq[u] < Sq;
         const int ic = valid[u] ? iq[u] : Sq - 1;
         qoff[u] = ((int64_t)b * Sq + ic) * ld + h * DH;
@@ -366,10 +386,12 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
 // Forward attention of the training path: o, and per (query, head) the log-sum-exp of the scores (base 2) in stats[..][0], so
 // that the backward needs no pass of its own to find it.  Thread = PT queries, online softmax over blocks of 8 keys.
 template <int DH, int PT, bool MASKED>
-__global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, const float* k, const float* v, int H, int Sq, int Skv, float scale,
-                                                              int mask_off, float* o, float* stats) {
+__global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, const float* k, const float* v, int B, int nx, int H, int Sq, int Skv,
+                                                              float scale, int mask_off, float* o, float* stats) {
     __shared__ float ks[128][DH], vs[128][DH];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const AttnBlock blk = attn_block(B, H, nx);
+    if (!blk.ok) return;
+    const int b = blk.b, h = blk.h, bx = blk.x;
     const int ld = H * DH;
     int iq[PT], last[PT];
     bool valid[PT];
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, con
     int last_all = 0;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-        iq[u] = blockIdx.x * (128 * PT) + 128 * u + threadIdx.x;
+        iq[u] = bx * (128 * PT) + 128 * u + threadIdx.x;
         valid[u] = iq[u] < Sq;
         const int ic = valid[u] ? iq[u] : Sq - 1;
         qoff[u] = ((int64_t)b * Sq + ic) * ld + h * DH;
@@ -461,9 +483,11 @@ __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, con
 // Pass over keys: thread = PT keys;  dv_j = sum_i P_ij dout_i,   dk_j = scale * sum_i dS_ij q_i.
 template <int DH, int PT, bool MASKED>
 __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const float* k, const float* v, const float* dout, const float* stats,
-                                                            int H, int Sq, int Skv, float scale, int mask_off, float* dk, float* dv) {
+                                                            int B, int nx, int H, int Sq, int Skv, float scale, int mask_off, float* dk, float* dv) {
     __shared__ float qsh[128][DH], gsh[128][DH], ssh[128][2];
-    const int b = blockIdx.z, h = blockIdx.y;
+    const AttnBlock blk = attn_block(B, H, nx);
+    if (!blk.ok) return;
+    const int b = blk.b, h = blk.h, bx = blk.x;
     const int ld = H * DH;
     int jk[PT], first[PT];
     bool valid[PT];
@@ -472,7 +496,7 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
     int first_all = Sq;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
-        jk[u] = blockIdx.x * (128 * PT) + 128 * u + threadIdx.x;
+        jk[u] = bx * (128 * PT) + 128 * u + threadIdx.x;
         valid[u] = jk[u] < Skv;
         const int jc = valid[u] ? jk[u] : Skv - 1;
         koff[u] = ((int64_t)b * Skv + jc) * ld + h * DH;
@@ -827,11 +851,12 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
         return done(hipGetLastError(), "attention_bwd");
     }
     const int PTr = dh <= 16 ? 2 : 1;                               // queries (keys) per thread: 2 while the registers allow it
-    const dim3 gq((Sq + 128 * PTr - 1) / (128 * PTr), H, B), gk((Skv + 128 * PTr - 1) / (128 * PTr), H, B);
+    const int nq = (Sq + 128 * PTr - 1) / (128 * PTr), nk = (Skv + 128 * PTr - 1) / (128 * PTr);
+    const dim3 gq(attn_grid(B, H, nq)), gk(attn_grid(B, H, nk));
 #define PT (DH_ <= 16 ? 2 : 1)
 #define ADX_ATTN_BWD3(DH, MASKED, LSE)                                                                                                                  \
-    hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE>), gq, dim3(128), 0, s, q, k, v, o, dout, H, Sq, Skv, scale, mask_off, dq, stats);  \
-    hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED>), gk, dim3(128), 0, s, q, k, v, dout, stats, H, Sq, Skv, scale, mask_off, dk, dv);
+    hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE>), gq, dim3(128), 0, s, q, k, v, o, dout, B, nq, H, Sq, Skv, scale, mask_off, dq, stats);  \
+    hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED>), gk, dim3(128), 0, s, q, k, v, dout, stats, B, nk, H, Sq, Skv, scale, mask_off, dk, dv);
 #define ADX_ATTN_BWD2(DH, MASKED) if (stats_have_lse) { ADX_ATTN_BWD3(DH, MASKED, true) } else { ADX_ATTN_BWD3(DH, MASKED, false) }
 #define ADX_ATTN_BWD(DH)                                              \
     case DH: {                                                        \
@@ -863,12 +888,13 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
         return done(hipGetLastError(), "attention_stats");
     }
     const int PTr = dh <= 16 ? 2 : 1;
-    const dim3 gq((Sq + 128 * PTr - 1) / (128 * PTr), H, B);
+    const int nq = (Sq + 128 * PTr - 1) / (128 * PTr);
+    const dim3 gq(attn_grid(B, H, nq));
 #define ADX_ATTN_FWD(DH)                                                                                                                         \
     case DH: {                                                                                                                                   \
         constexpr int PT = DH <= 16 ? 2 : 1;                                                                                                     \
-        if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false>), gq, dim3(128), 0, s, q, k, v, H, Sq, Skv, scale, mask_off, o, stats); \
-        else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true>), gq, dim3(128), 0, s, q, k, v, H, Sq, Skv, scale, mask_off, o, stats);     \
+        if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats); \
+        else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats);     \
         break; }
     switch (dh) {
         ADX_ATTN_FWD(4)
