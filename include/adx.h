@@ -223,9 +223,10 @@ int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t,
                         float* loss_mean, int n_rows, int row_len, void* stream);
 
 /* --------------------------------------------------------------------------------------------
- * Backward operators of the refiner's training path (fp32).  The reference differentiates its loss with torch autograd
- * (loss.backward() on TrajRefiner.py:417-452 over transformer.py:189-273); each entry point below is the backward of one forward
- * operator above.  dX of a Linear is adx_op_linear on the transposed weight (adx_op_transpose).  Reductions over rows are
+ * Operators of the training paths (fp32): the refiner, the flattened wrapper and the decoder twin.  The reference differentiates
+ * its losses with torch autograd (loss.backward() on TrajRefiner.py:417-452 over transformer.py:189-273; diffusion_decoder.py:346-365
+ * over libs/diffusionTransformer.py:24-199); the entry points below are the backward of the forward operators above, plus the few
+ * forward operators a training forward needs on their own (activations, products, attention with kept statistics).  dX of a Linear is adx_op_linear on the transposed weight (adx_op_transpose).  Reductions over rows are
  * summed per row chunk and combined in a fixed order: results do not depend on launch timing.
  * ------------------------------------------------------------------------------------------ */
 int adx_op_add(const float* a, const float* b, float* out, int64_t n, void* stream);              /* residual adds, gradient sums */
