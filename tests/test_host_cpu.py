@@ -373,3 +373,26 @@ def test_training_path_host_logic():
     assert w.shape == (3, 2) and not w.any() and g.of("a.weight") is w and g.of("a.bias").shape == (3,)
     w += 1
     assert float(g.flat.sum()) == 6.0 and set(g.g) == {"a.weight", "a.bias"}
+
+
+def test_training_operators_reject_bad_arguments():
+    """Argument checks of the training entry points through the raw ABI: they answer before any device work, so this runs
+    without a GPU (null pointers, empty shapes, unsupported head widths, scratch buffers that are too small)."""
+    import ctypes as C
+    from autodiffusion_amd import _lib
+    lib = _lib.load()
+    fake = 4096                                  # never dereferenced: every call below is refused by its checks
+    assert lib.adx_op_add(None, fake, fake, 8, None) == 1
+    assert lib.adx_op_act(fake, fake, 8, 99, None) == 1 and b"activation" in lib.adx_last_error()
+    assert lib.adx_op_linear_wgrad(fake, fake, 0, 4, 4, fake, None, 0, fake, 1 << 20, None) == 1
+    need = lib.adx_reduce_ws_bytes(1000, 32, 32)
+    assert need == ((1000 + 31) // 32) * (32 * 32 + 32) * 4          # 32 chunks of 32 rows, a dW tile and a bias row each
+    assert lib.adx_op_linear_wgrad(fake, fake, 1000, 32, 32, fake, None, 0, fake, need - 1, None) == 1
+    assert b"workspace" in lib.adx_last_error()
+    assert lib.adx_op_colsum(fake, 10, 4, fake, 0, fake, 0, None) == 1
+    args = (fake, fake, fake, fake, fake, 2, 8, 10, 10)
+    assert lib.adx_op_attention_bwd(*args, 12, C.c_float(0.5), -1, fake, fake, fake, fake, 0, None) == 1
+    assert b"head width" in lib.adx_last_error()
+    assert lib.adx_op_attention_stats(fake, fake, fake, fake, fake, 2, 8, 200, 200, 64, C.c_float(0.5), -1, None) == 1   # 200 tokens: no LDS room
+    assert lib.adx_op_group_colsum(fake, 70000, 80, 64, fake, None) == 1
+    assert lib.adx_op_layernorm_bwd(fake, None, fake, 0, 32, C.c_float(1e-5), fake, None, None) == 1
