@@ -13,6 +13,16 @@ import torch
 import torch.distributed as dist
 
 
+def free_port(host: str = "127.0.0.1") -> int:
+    """A TCP port nobody listens on right now (bound to port 0, read back, released): the rendezvous port of a process group
+    started from here.  Two launches on one host get different ports, which a port derived from the process id does not promise."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind((host, 0))
+        return int(s.getsockname()[1])
+
+
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     """Rows [lo, hi) owned by ``rank``: contiguous, sizes differ by at most one, earlier ranks get the extras."""
     base, extra = divmod(total, world)

@@ -84,6 +84,49 @@ def reference_init_(module: torch.nn.Module, seed: int) -> torch.nn.Module:
     return module
 
 
+def contractive_dit_init_(module: torch.nn.Module, seed: int, readout_scale: float = 1.0, gate: float = 0.05, mod: float = 0.3,
+                         side: float = 0.1) -> torch.nn.Module:
+    """Seeded weights under which the DiT / MM-DiT decoder behaves like a TRAINED denoiser inside the sampler.
+
+    An untrained decoder returns eps unrelated to x_t, the DDPM recursion then multiplies x by 1/sqrt(alpha_t) per step and the
+    +-max_action clamp is what bounds the sample: final coordinates of thousands of metres, on which an error in metres says
+    nothing.  Here every tensor starts from :func:`seeded_param` (all layers active, activations of order one) and four changes
+    make eps = x_t * (1 + small) + r(x_t, t, state), |r| a fraction of |x_t|, which is the contraction a trained denoiser gives
+    (x0 estimates inside the data range, final trajectories of tens of metres):
+
+    * the trajectory encoder's ``fc`` matrices carry an identity from their first four inputs to their first four outputs (their
+      other contributions to those outputs scaled by ``side``), and the position table is zero on those four features, so the
+      residual stream holds x_t in features 0..3;
+    * gate rows of every ``adaLN_modulation`` product are scaled by ``gate`` (the blocks perturb the stream instead of replacing
+      it), shift / scale rows by ``mod``;
+    * the final linear layer reads features 0..3 back with ``readout_scale`` (the factor that undoes the final LayerNorm's
+      division by the stream's standard deviation; measured once per configuration) plus ``side`` times its seeded matrix.
+    """
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            x = seeded_param(n, tuple(p.shape), seed)
+            leaf = n.split(".")
+            if "adaLN_modulation" in n:
+                chunks = 2 if "final_layer" in n else 6
+                rows = x.shape[0] // chunks
+                for c in range(chunks):
+                    is_gate = chunks == 6 and c in (2, 5)
+                    x[c * rows:(c + 1) * rows] *= (gate if is_gate else mod * (0.3 if chunks == 2 else 1.0))
+            elif "x_encoder." in n and leaf[-2] == "fc":
+                x[:4] *= side
+                if leaf[-1] == "weight":
+                    x[:4, :4] += torch.eye(4)
+            elif leaf[-1] == "position_embedding":
+                x[..., :4] = 0
+            elif "final_layer.linear" in n:
+                x *= side
+                if leaf[-1] == "weight":
+                    k = min(x.shape[0], 4)
+                    x[:k, :k] += readout_scale * torch.eye(k)
+            p.copy_(x.to(p.dtype))
+    return module
+
+
 def _rows(seed: int, tag: str, row0: int, nrows: int, tail: Tuple[int, ...]) -> np.ndarray:
     """Standard-normal block whose row r only depends on (seed, tag, global row r)."""
     out = np.empty((nrows,) + tail, dtype=np.float32)

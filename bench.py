@@ -316,7 +316,8 @@ def train_step(dev, B=64, steps=5):
 def launch_ranks(args):
     """--gpus N without a launcher: start the N ranks as a fresh child (never from a process that initialised a GPU) and
     relay its output; rank 0 of the child prints the JSON line."""
-    port = 29500 + os.getpid() % 2000
+    from autodiffusion_amd.distributed import free_port
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)

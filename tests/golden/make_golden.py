@@ -325,6 +325,13 @@ def g9_dit_loop():
             traj = dec.model(state, batch_size=B, determin=False)
             assert not q, len(q)
         out[f"{backbone}_stochastic"] = traj
+        # the sample score the loop accumulates beside the sample (diffusion_decoder.py:394,404,446): sample_forward drops it, so
+        # the loop itself is called; its first result is the normalised sample
+        with torch.no_grad(), noise_queue([nz[0]] + [nz[1 + i] for i in range(N)]) as q:
+            x_norm, total_cls = dec.model.p_sample_loop(state, (B, 80, 4), determin=False)
+            assert not q, len(q)
+        assert torch.equal(ref_utils.denormalize(x_norm), traj)
+        out[f"{backbone}_total_cls"] = total_cls
     save("g9_dit_loop", **out)
 
 
@@ -581,8 +588,40 @@ def g16_mmdit_grads():
     g15_twin_grads("MM-DiT", "g16_mmdit_grads")
 
 
+# ----------------------------------------------------------------------------- G17: C5 at its own depth and loop length
+def g17_c5_loop():
+    """BASELINE configs[4] as configured: DiT hidden 1024, 24 blocks, 16 heads, 200-step ancestral DDPM (cosine), stochastic, B = 2,
+    through the reference's own DiffusionWrapper.p_sample_loop with supplied noise.  Weights: synth.contractive_dit_init_ (seeded;
+    the sampler contracts as with a trained denoiser, so the final trajectories are tens of metres and an error in metres means
+    something).  Stored: the readout scale the weights were made with, x_t and the denoiser output of every step, the final
+    trajectories and the sample scores.  Takes a few minutes on 8 cores (0.68 G parameters, 200 denoiser calls)."""
+    B, N, d, L, h = 2, 200, 1024, 24, 16
+    dec = ref_dd.DiffusionDecoder(dit_config(d, L, h, "DiT", n=N))
+    synth.contractive_dit_init_(dec.model.model, WSEED, readout_scale=C5_READOUT, gate=C5_GATE)
+    dec = dec.float().eval()
+    state = synth.hidden_state(B, d, ISEED)
+    nz = synth.noise(B, (N + 1,), (80, 4), NSEED)
+    net = dec.model.model
+    xs, outs = [], []
+
+    def hook(mod, args, o):
+        xs.append(args[0].detach().clone())
+        outs.append(o.detach().clone())
+    hk = net.register_forward_hook(hook)
+    with torch.no_grad(), noise_queue([nz[0]] + [nz[1 + i] for i in range(N)]) as q:
+        x_norm, total_cls = dec.model.p_sample_loop(state, (B, 80, 4), determin=False)
+        assert not q, len(q)
+    hk.remove()
+    traj = ref_utils.denormalize(x_norm)
+    print("g17: |trajectory| mean", float(traj[..., :2].abs().mean()), "max", float(traj.abs().max()))
+    save("g17_c5_loop", readout_scale=np.float32(C5_READOUT), gate=np.float32(C5_GATE), x=torch.stack(xs), model_out=torch.stack(outs),
+         traj=traj, total_cls=total_cls)
+
+
+C5_READOUT, C5_GATE = 0.93, 0.1
+
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
-       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads}
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

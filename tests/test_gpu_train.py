@@ -222,7 +222,8 @@ def test_distributed_data_parallel_wraps_the_training_path(dev):
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    from autodiffusion_amd.distributed import free_port
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     fs, N, B = 10, 100, 4
     maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED).to(dev)

@@ -226,7 +226,8 @@ print("ok", rank)
 def test_two_rank_gloo_shard_and_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = str(29500 + os.getpid() % 2000)
+    from autodiffusion_amd.distributed import free_port
+    port = str(free_port())
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     for p in procs:

@@ -267,7 +267,37 @@ def test_dit_twin_loop(golden, backbone):
     noise = synth.noise(2, (11,), (80, 4), NSEED)
     sto, cls = sampling.twin_sample(fn, b, (2, 80, 4), noise, determin=False)
     assert rel_err(sto, g[f"{backbone}_stochastic"]) < 2e-4
-    np.testing.assert_allclose(cls.numpy(), -(noise ** 2).mean(dim=2).sum(0).numpy(), rtol=1e-5)
+    # the sample score as the reference's own loop accumulated it (diffusion_decoder.py:394,404,446)
+    np.testing.assert_allclose(cls.numpy(), g[f"{backbone}_total_cls"], rtol=1e-5)
+
+
+# ------------------------------------------------------------------ G17: the scaled decoder at its own depth and loop length
+def test_c5_full_depth_steps(golden):
+    """DiT hidden 1024, 24 blocks, 16 heads, 200-step DDPM, contractive weights: the oracle's denoiser on the recorded x_t of a few
+    steps, its step update from one recorded step to the next, and the recording's own sanity (no sample near the clamp: the
+    metres of the trajectories mean something)."""
+    g = golden("g17_c5_loop")
+    from autodiffusion_amd import dit
+    N, h = 200, 16
+    m = dit.Transformer_TrajDiffusionModel(dit.dit_config(1024, 24, h, "DiT"))
+    synth.contractive_dit_init_(m, WSEED, readout_scale=float(g["readout_scale"]), gate=float(g["gate"]))
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    state = synth.hidden_state(2, 1024, ISEED)
+    noise = synth.noise(2, (N + 1,), (80, 4), NSEED)
+    assert torch.equal(T(g["x"][0]), noise[0])
+    b = schedules.buffers_from_betas(schedules.twin_betas("cosine", N), f32=True)
+    traj = T(g["traj"])
+    assert float(traj[..., :2].abs().max()) < 250.0 and float(traj[..., :2].abs().mean()) > 2.0
+    for i in (0, 57, 199):
+        t = N - 1 - i
+        out = nets.dit_forward(sd, T(g["x"][i]), torch.full((2,), t, dtype=torch.long), state, h, "DiT")
+        assert rel_err(out, g["model_out"][i]) < 1e-4, i
+        if i + 1 < N:        # one step of the loop from the recorded state: x_{t-1} = mean(clamp(x0)) + sigma z
+            x0 = sampling.x0_from_output(b, "pred_noise", T(g["x"][i]), T(g["model_out"][i]), t).clamp(-100, 100)
+            mean = float(b["posterior_mean_coef1"][t]) * x0 + float(b["posterior_mean_coef2"][t]) * T(g["x"][i])
+            nxt = mean + float(np.exp(0.5 * b["posterior_log_variance_clipped"][t])) * noise[1 + i]
+            assert rel_err(nxt, g["x"][i + 1]) < 1e-5, i
+    np.testing.assert_allclose(g["total_cls"], -(noise ** 2).mean(dim=2).sum(0).numpy(), rtol=2e-5)
 
 
 # ------------------------------------------------------------------ diffusers-style steps: analytic known answers (parity unpinned)
