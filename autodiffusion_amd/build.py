@@ -27,18 +27,24 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, measure: bool = False) -> str:
+    """``measure``: the measurement library ``libadx_measure.so`` (-DADX_MEASURE): the same code plus the kernel instances with
+    parts switched off that the ablation scripts under ``profiles/`` select through ``ADX_*_ABLATE`` -- their results are wrong
+    on purpose, so they are compiled out of ``libadx.so``; ``ADX_LIB_PATH`` makes ``_lib.load()`` take the other library."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir = OBJ + ("_measure" if measure else "")
+    out = os.path.join(HERE, "libadx_measure.so") if measure else OUT
+    flags = FLAGS + (["-DADX_MEASURE"] if measure else [])
+    os.makedirs(obj_dir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -51,10 +57,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(OUT, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
-    return OUT
+    if jobs or force or _stale(out, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, measure="--measure" in sys.argv))

@@ -862,6 +862,7 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
         else if (waves == 3) hipLaunchKernelGGL((enc_rows_kernel<P, 3, G, T>), dim3(blocks), dim3(256), smem, stream, a); \
         else hipLaunchKernelGGL((enc_rows_kernel<P, 2, G, T>), dim3(blocks), dim3(256), smem, stream, a);                 \
     } while (0)
+#ifdef ADX_MEASURE          // measurement library only: the ablation instances give wrong results
 #define ADX_LAUNCH_ROWS(P)                                       \
     do {                                                         \
         if (a.gpk && a.gates && abl && waves == 3) {             \
@@ -880,9 +881,17 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
         else if (a.gpk) ADX_LAUNCH_ROWS2(P, true, false);        \
         else ADX_LAUNCH_ROWS2(P, false, false);                  \
     } while (0)
-    if (a.gates && !a.gpk) return hipErrorInvalidValue;          // the gate table exists for the LayerNorm-row form only
     const char* abl_env = getenv("ADX_ENC_ROWS_ABLATE");         // measurement aid, read per call (split-bf16 mode only)
     const int abl = (abl_env && prec == PREC_BF16X3) ? atoi(abl_env) : 0;
+#else
+#define ADX_LAUNCH_ROWS(P)                                       \
+    do {                                                         \
+        if (a.gpk && a.gates) ADX_LAUNCH_ROWS2(P, true, true);   \
+        else if (a.gpk) ADX_LAUNCH_ROWS2(P, true, false);        \
+        else ADX_LAUNCH_ROWS2(P, false, false);                  \
+    } while (0)
+#endif
+    if (a.gates && !a.gpk) return hipErrorInvalidValue;          // the gate table exists for the LayerNorm-row form only
     if (!a.gpk && !a.kv) return hipErrorInvalidValue;
     if (prec == PREC_F32) ADX_LAUNCH_ROWS(PREC_F32);
     else if (prec == PREC_BF16) ADX_LAUNCH_ROWS(PREC_BF16);
@@ -917,7 +926,8 @@ hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream) {
     if (prec == PREC_F32) hipLaunchKernelGGL(attn_g_kernel<PREC_F32>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
     else if (prec == PREC_BF16) hipLaunchKernelGGL(attn_g_kernel<PREC_BF16>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
     else {
-        const char* abl_env = getenv("ADX_ATTN_G_ABLATE");      // measurement aid, read per call
+#ifdef ADX_MEASURE
+        const char* abl_env = getenv("ADX_ATTN_G_ABLATE");      // measurement aid, read per call (measurement library only)
         switch (abl_env ? atoi(abl_env) : 0) {
             case 1: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 1>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
             case 2: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 2>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
@@ -929,6 +939,9 @@ hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream) {
             case 16: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 16>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf); break;
             default: hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
         }
+#else
+        hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+#endif
     }
     return hipGetLastError();
 }

@@ -1040,10 +1040,11 @@ __global__ __launch_bounds__(256) void stage_w_kernel(const unsigned short* __re
 template <bool X3>
 static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
     constexpr size_t smem = (X3 ? 4 : 8) * (X3 ? 4 : 2) * (size_t)GIMG_B;      // ring of K-step buffers: 128 KB
+    auto kern = &linear_glds_kernel<X3, 0>;
+#ifdef ADX_MEASURE          // measurement library only (python -m autodiffusion_amd.build --measure): instances whose results are wrong
     const char* abl_env = getenv("ADX_GLDS_ABLATE");        // read per call
     const int abl = abl_env ? atoi(abl_env) : 0;
-    auto kern = &linear_glds_kernel<X3, 0>;
-    switch (abl) {          // measurement aid: bit 0 no LDS reads, bit 1 no copies, bit 2 no MFMAs, bit 3 no epilogue (results are wrong)
+    switch (abl) {          // bit 0 no LDS reads, bit 1 no copies, bit 2 no MFMAs, bit 3 no epilogue
         case 1: kern = &linear_glds_kernel<X3, 1>; break;
         case 2: kern = &linear_glds_kernel<X3, 2>; break;
         case 3: kern = &linear_glds_kernel<X3, 3>; break;
@@ -1052,6 +1053,9 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
         case 11: kern = &linear_glds_kernel<X3, 11>; break;
         default: break;
     }
+#else
+    constexpr int abl = 0;
+#endif
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return hipErrorInvalidValue;
     const size_t xe = a.Xh ? 0 : (size_t)a.M * a.K, we = (size_t)a.N * a.K;          // scratch layout: [X planes unless given][W planes unless given]
     unsigned short* base = reinterpret_cast<unsigned short*>(a.xstage);
@@ -1081,6 +1085,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
     if (form == 2) {
         constexpr size_t smem2 = (X3 ? 3 : 6) * (X3 ? 2 : 1) * (size_t)(G2_A_B + G2_B_B);      // 72 KB: two workgroups per CU
         auto kern2 = &linear_glds2_kernel<X3, 16>;
+#ifdef ADX_MEASURE
         switch (abl) {      // measurement aid, as above (32: the un-interleaved step)
             case 32: kern2 = &linear_glds2_kernel<X3, 0>; break;
             case 1: kern2 = &linear_glds2_kernel<X3, 1>; break;
@@ -1100,6 +1105,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
             case 144: kern2 = &linear_glds2_kernel<X3, 144>; break;
             default: break;
         }
+#endif
         if constexpr (!X3) {            // single-pass bf16 can walk its 6-slot ring 2 or 3 K-steps per barrier.  Measured (M=20480 N=4096 K=1024,
             // product kernel alone): 1 step 226.6 us, 2 steps 232.8, 3 steps 247.0 -- the barrier is not what limits this kernel
             const char* ks_env = getenv("ADX_GLDS_KSTEPS");      // tuning knob, read per call
@@ -1551,6 +1557,7 @@ static hipError_t launch_mlp256(const LinearArgs& a1, const LinearArgs& a2, hipS
         hipLaunchKernelGGL((mlp256_kernel<X3, ACT>), grid, block, smem, stream, a1, a2);                                           \
         return hipGetLastError();                                                                                                  \
     }
+#ifdef ADX_MEASURE
     if (X3 && a1.act == ACT_RELU) {                 // measurement hooks (results are wrong): 1 no weight copies after the first, 2 / 4 no products in phase 2 / 1, 8 no epilogue loads and stores, 16 no X loads
         const char* e = getenv("ADX_MLP_ABLATE");
         const int abl = e ? atoi(e) : 0;
@@ -1565,6 +1572,7 @@ static hipError_t launch_mlp256(const LinearArgs& a1, const LinearArgs& a2, hipS
         ADX_MLP_ABL(1) ADX_MLP_ABL(2) ADX_MLP_ABL(4) ADX_MLP_ABL(6) ADX_MLP_ABL(7) ADX_MLP_ABL(15) ADX_MLP_ABL(23) ADX_MLP_ABL(31) ADX_MLP_ABL(24)
 #undef ADX_MLP_ABL
     }
+#endif
     switch (a1.act) {
         case ACT_RELU: ADX_MLP_LAUNCH(ACT_RELU)
         case ACT_GELU_TANH: ADX_MLP_LAUNCH(ACT_GELU_TANH)

@@ -6,7 +6,7 @@ the host-side tests and by callers that already hold the trajectories on the hos
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Tuple
 
 import torch
 
@@ -58,9 +58,46 @@ def ade_fde(pred: torch.Tensor, label: torch.Tensor) -> Dict[str, torch.Tensor]:
     return {k: t[:, i] for i, k in enumerate(COLUMNS[:8])}
 
 
-def compute_metrics(pred: torch.Tensor, label: torch.Tensor) -> Dict[str, float]:
-    """Batch means under the reference's result keys (``*_gen`` horizons, ``metric_*``, scores, miss rates)."""
-    t = per_scenario(pred, label).double()
+def compute_scores(table: torch.Tensor, scenario15s_id) -> Tuple[float, float]:
+    """``compute_scores`` of the evaluation entry (transformer4planning/utils/nuplan_utils.py:229-314; called at trainer.py:363):
+    the frames (rows of the (B, 18) per-frame ``table``) are grouped by ``scenario15s_id``; per group and per quantity q in
+    {ade, fde, ahe, fhe}: ``q_score = max(1 - mean_over_frames(q3 + q5 + q8) / 3 / threshold, 0)`` -- the clamp acts on the GROUP
+    mean, unlike the per-frame ``*_score`` keys of ``compute_metrics``; ``miss_score = 0`` if five or more frames of the group
+    miss (maximum displacement above 6 / 8 / 16 m within 3 / 5 / 8 s), else 1; ``score = miss_score * (ade + fde + 2 ahe +
+    2 fhe) / 6``.  Returns (mean score over groups, mean miss_score over groups).  Two-channel trajectories have no heading
+    columns (zeros): their heading scores are 1, where the reference raises a KeyError that its caller turns into (0, 0).
+
+    No reference output pins this function: its module does not import here (``shapely`` is absent); it is checked against a
+    restatement of the same lines and analytic cases."""
+    t = table.detach().double().cpu()
+    ids = torch.as_tensor(scenario15s_id).reshape(-1).to(torch.int64).cpu()
+    if ids.shape[0] != t.shape[0]:
+        raise ValueError(f"{t.shape[0]} frames but {ids.shape[0]} scenario ids")
+    c = {k: t[:, i] for i, k in enumerate(COLUMNS)}
+    _, inv = torch.unique(ids, return_inverse=True)
+    n_groups = int(inv.max()) + 1 if inv.numel() else 0
+    if n_groups == 0:
+        return 0.0, 0.0
+    count = torch.zeros(n_groups, dtype=torch.float64).index_add_(0, inv, torch.ones_like(inv, dtype=torch.float64))
+
+    def group_mean(v):
+        return torch.zeros(n_groups, dtype=torch.float64).index_add_(0, inv, v) / count
+
+    def score(q, threshold):
+        return (1 - group_mean(c[f"{q}3"] + c[f"{q}5"] + c[f"{q}8"]) / 3 / threshold).clamp(min=0)
+    miss = ((c["maxd3"] > MISS_THRESHOLD[0]) | (c["maxd5"] > MISS_THRESHOLD[1]) | (c["maxd8"] > MISS_THRESHOLD[2])).double()
+    n_miss = torch.zeros(n_groups, dtype=torch.float64).index_add_(0, inv, miss)
+    miss_score = (n_miss < 5).double()
+    total = (score("ade", ADE_THRESHOLD) + score("fde", FDE_THRESHOLD) + 2 * score("ahe", HEADING_ERROR_THRESHOLD)
+             + 2 * score("fhe", HEADING_ERROR_THRESHOLD)) / 6
+    return float((miss_score * total).mean()), float(miss_score.mean())
+
+
+def compute_metrics(pred: torch.Tensor, label: torch.Tensor, scenario15s_id=None) -> Dict[str, float]:
+    """Batch means under the reference's result keys (``*_gen`` horizons, ``metric_*``, per-frame scores, miss rates); with
+    ``scenario15s_id`` (one id per frame) also ``average_score`` and ``miss_score`` of :func:`compute_scores`."""
+    table = per_scenario(pred, label)
+    t = table.double()
     c = {k: t[:, i] for i, k in enumerate(COLUMNS)}
     r: Dict[str, float] = {}
     for n in (1, 3, 5, 8):
@@ -84,4 +121,6 @@ def compute_metrics(pred: torch.Tensor, label: torch.Tensor) -> Dict[str, float]
     miss = [(c[f"maxd{n}"] > th).double() for n, th in zip((3, 5, 8), MISS_THRESHOLD)]
     r["miss_rate3"], r["miss_rate5"], r["miss_rate8"] = (float(m.mean()) for m in miss)
     r["total_miss_rate"] = float(((miss[0] + miss[1] + miss[2]) >= 1).double().mean())
+    if scenario15s_id is not None:
+        r["average_score"], r["miss_score"] = compute_scores(table, scenario15s_id)
     return r

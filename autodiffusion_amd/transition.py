@@ -12,7 +12,9 @@ The reference imports the denoiser of this variant (``TransformerForDiffusion``,
 recovered.  Here ``z`` takes the transition slot of the encoder/decoder ``Transformer`` (whose embedding of that slot
 is named ``prior_z_emb``) through one extra Linear ``z_emb (z_dim -> prior_dim)``; everything else is the reference's
 ``Transformer`` with ``output_dim = z_dim``.  The scheduler follows the public DDPMScheduler semantics
-(``schedules.diffusers_rows``).  Every product runs in the HIP library; the step loop is host-side.
+(``schedules.diffusers_rows``).  Every product runs in the HIP library; the step loop is host-side.  ``forward()`` of both
+classes returns the evaluation-time VALUE of the training loss (StrDiffDiT.py:96-155, diffusion_transition.py:95-130) without
+an autograd graph.
 """
 from __future__ import annotations
 
@@ -78,8 +80,36 @@ class DiffusionTransitionModel(nn.Module):
             trajectory = ops.sched_step(trajectory, model_output, noise[zi] if zi >= 0 else None, row)
         return z_output, trajectory
 
-    def forward(self, z, x, cond, prior):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path")
+    def train_tables(self):
+        """sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod) of the training schedule (what DDPMScheduler.add_noise reads)."""
+        sc = self.cfg.scheduler
+        ac = torch.cumprod(1.0 - schedules.diffusers_betas(sc.beta_schedule, sc.num_train_timesteps, sc.beta_start, sc.beta_end), dim=0)
+        return ac.sqrt(), (1.0 - ac).sqrt()
+
+    @torch.no_grad()
+    def forward(self, z, x, cond, prior, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """One training-style evaluation of a chunk (diffusion_transition.py:95-130), VALUE ONLY: noise the chunk ``x (B, fs, 4)``
+        at one random timestep per row in [1, num_train_timesteps), one denoiser call with the latent ``z``, ``x_from_z`` ->
+        (pred_z (B, fs, z_dim), pred_x (B, fs, 4), target = the noise).  ``t`` / ``noise`` supply the two draws.  Runs without
+        autograd: the results carry no graph, so ``backward()`` on a loss built from them raises -- the training of this
+        variant is not built (its denoiser class is missing from the reference tree)."""
+        x = _lib.f32c(x)
+        B = x.shape[0]
+        n_train = int(self.cfg.scheduler.num_train_timesteps)
+        if noise is None:
+            noise = torch.randn(x.shape, device=x.device)
+        if t is None:
+            t = torch.randint(1, n_train, (B,), device=x.device)
+        t = t.to(device=x.device, dtype=torch.int64)
+        sa, s1 = self.train_tables()
+        noisy_x, _ = ops.q_sample(x, _lib.f32c(noise), t, sa, s1)
+        transition = ops.linear(_lib.f32c(z), self.z_emb.weight, self.z_emb.bias)
+        condition = dict(maps_info=_lib.f32c(cond), transition_info=transition, trajectory_prior=_lib.f32c(prior))
+        pred_z = self.diffusion(noisy_x, t, condition)
+        pred_x = ops.linear(pred_z, self.x_from_z.weight, self.x_from_z.bias)
+        if self.cfg.scheduler.prediction_type != "epsilon":
+            raise ValueError(f"Unsupported prediction type {self.cfg.scheduler.prediction_type}")
+        return pred_z, pred_x, noise
 
 
 class StrDiffDiT(nn.Module):
@@ -142,8 +172,47 @@ class StrDiffDiT(nn.Module):
         out = torch.stack(preds, dim=1).reshape(B, S, C)
         return {"traj_logits": self._unnormalize_x(out).to(torch.float32)}
 
-    def forward(self, return_dict=None, **kwargs):
-        raise NotImplementedError("training forward (diffusion loss) is outside the accelerated sampling path; use generate()")
+    def _normalize_x(self, xs):
+        return (xs - self.data_mean.to(xs.device)) / self.data_std.to(xs.device)
+
+    @torch.no_grad()
+    def forward(self, return_dict=None, t: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, **kwargs):
+        """The loss the evaluation entry reports for this wrapper (StrDiffDiT.py:96-155), VALUE ONLY (no autograd graph; see
+        DiffusionTransitionModel.forward).  As the reference does, the chunks that are noised are those of the normalised
+        trajectory PRIOR (its ``_preprocess_batch`` takes ``xs = batch[1]``, the prior: the label never enters the loss), the
+        conditioning prior has its first frame zeroed and stays un-normalised, the latent returned by a chunk conditions the
+        next, the loss is the plain mean of the element-wise squared error, and ``logits`` is the un-normalised ``x_from_z``
+        output re-assembled to (B, 80, 4).  ``t`` (n_chunks, B) and ``noise`` (n_chunks, B, fs, 4) supply the draws."""
+        from .refiner import LTMOutput
+        if "trajectory_prior" in kwargs and "maps_info" in kwargs:
+            trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
+        else:
+            if self.str_model[0] is None:
+                raise ValueError("forward() needs either trajectory_prior/maps_info or a str_model for phase 1")
+            str_result = self.str_model[0].generate(**kwargs)
+            trajectory_prior, maps_info = str_result["traj_logits"], str_result["maps_info"]
+        B, S, C = trajectory_prior.shape
+        if S % self.frame_stack != 0:
+            raise ValueError("Number of frames must be divisible by frame stack size")
+        if getattr(self.cfg, "context_frames", 0) % self.frame_stack != 0:
+            raise ValueError("Number of context frames must be divisible by frame stack size")
+        n_chunks, fs = S // self.frame_stack, self.frame_stack
+        prior = _lib.f32c(trajectory_prior)
+        conditions = prior.clone()
+        conditions[:, :1] = 0.0
+        conditions = conditions.reshape(B, n_chunks, fs, C)
+        xs = self._normalize_x(prior).reshape(B, n_chunks, fs, C)
+        z = self.init_z[None].expand(B, *self.z_shape).contiguous() if self.learnable_init_z else torch.zeros(B, *self.z_shape, device=prior.device)
+        preds, losses = [], []
+        for c in range(n_chunks):
+            z, pred_x, target = self.transition_model(z, xs[:, c].contiguous(), maps_info, conditions[:, c].contiguous(),
+                                                      t=None if t is None else t[c], noise=None if noise is None else noise[c])
+            preds.append(pred_x)
+            losses.append((pred_x - target) ** 2)
+        loss_items = torch.stack(losses)                                          # (n_chunks, B, fs, C)
+        logits = self._unnormalize_x(torch.stack(preds, dim=1).reshape(B, S, C))
+        return LTMOutput(loss=loss_items.mean(), loss_items=loss_items, logits=logits, pred_dict={"traj_logits": logits},
+                         trajectory_label=self._unnormalize_x(xs.permute(1, 0, 2, 3)))
 
 
 def transition_config(frame_stack: int = 10, z_dim: int = 768, num_train_timesteps: int = 100, num_inference_steps: int = 10,

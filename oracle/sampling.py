@@ -379,6 +379,33 @@ def transition_generate(denoise_z: Callable, z_emb: Callable, x_from_z: Callable
     return out * std + mean
 
 
+def transition_forward(denoise_z: Callable, z_emb: Callable, x_from_z: Callable, ac: np.ndarray, prior_full, init_z, t, noise,
+                       frame_stack: int, data_mean, data_std):
+    """Loss of the latent-carrying wrapper's forward() (StrDiffDiT.py:96-155 with DiffusionTransitionModel.forward,
+    diffusion_transition.py:95-130; ``add_noise`` per the public DDPMScheduler semantics).  Parity unpinned, like
+    :func:`transition_generate`.  The noised chunks are those of the NORMALISED PRIOR (StrDiffDiT.py:163: ``xs = batch[1]``);
+    ``t`` (n_chunks, B) int64 in [1, N), ``noise`` (n_chunks, B, fs, 4).  Returns (loss, un-normalised predictions (B, S, 4))."""
+    B, S, C = prior_full.shape
+    n_chunks = S // frame_stack
+    mean = torch.as_tensor(data_mean, dtype=torch.float32)
+    std = torch.as_tensor(data_std, dtype=torch.float32)
+    cond = prior_full.clone()
+    cond[:, :1] = 0.0
+    cond = cond.reshape(B, n_chunks, frame_stack, C)
+    xs = ((prior_full - mean) / std).reshape(B, n_chunks, frame_stack, C)
+    sa = torch.as_tensor(np.sqrt(ac), dtype=torch.float32)
+    s1 = torch.as_tensor(np.sqrt(1.0 - ac), dtype=torch.float32)
+    z = init_z[None].expand(B, *init_z.shape)
+    preds, losses = [], []
+    for c in range(n_chunks):
+        noisy = sa[t[c]][:, None, None] * xs[:, c] + s1[t[c]][:, None, None] * noise[c]
+        z = denoise_z(noisy, t[c], z_emb(z), cond[:, c])
+        pred = x_from_z(z)
+        preds.append(pred)
+        losses.append((pred - noise[c]) ** 2)
+    return torch.stack(losses).mean(), torch.stack(preds, dim=1).reshape(B, S, C) * std + mean
+
+
 # ------------------------------------------------------------------ metrics
 def displacement_metrics(pred: np.ndarray, label: np.ndarray) -> Dict[str, np.ndarray]:
     """ADE/FDE at 1/3/5/8 s per scenario (trainer.py:184-234): L2 over (x, y) per point."""
@@ -421,3 +448,34 @@ def evaluation_metrics(pred: np.ndarray, label: np.ndarray) -> Dict[str, float]:
     r["miss_rate3"], r["miss_rate5"], r["miss_rate8"] = (m.mean() for m in miss)
     r["total_miss_rate"] = ((miss[0] + miss[1] + miss[2]) >= 1).astype(np.float64).mean()
     return {k: float(v) for k, v in r.items()}
+
+
+def evaluation_scores(pred: np.ndarray, label: np.ndarray, scenario15s_id) -> tuple:
+    """``compute_scores`` (utils/nuplan_utils.py:229-314) on the per-frame items ``compute_metrics`` saves (trainer.py:196-301):
+    frames grouped by scenario id in order of first appearance; per group the mean over frames of (h3 + h5 + h8), divided by 3 and
+    by the threshold, subtracted from 1 and clamped at 0, for ADE / FDE (8 m) and AHE / FHE (0.8 rad); ``miss_score`` 0 when the
+    group has 5 or more missed frames; ``score = miss_score * (ade + fde + 2 ahe + 2 fhe) / 6``.  Plain loops, as the reference.
+    Returns (average score, average miss_score).  Parity unpinned: the reference module needs ``shapely`` to import."""
+    S = label.shape[1]
+    rs = int(80 / S) if S < 80 else 1
+    err = np.sqrt((pred[..., 0] - label[..., 0]) ** 2 + (pred[..., 1] - label[..., 1]) ** 2)
+    wrap = lambda a: np.arctan2(np.sin(a), np.cos(a))  # noqa: E731
+    he = np.abs(wrap(wrap(pred[..., -1]) - wrap(label[..., -1])))
+    groups: dict = {}
+    for i, sid in enumerate(scenario15s_id):
+        groups.setdefault(int(sid), []).append(i)
+    scores, miss_scores = [], []
+    for sid, frames in groups.items():
+        sums = {"ade": [], "fde": [], "ahe": [], "fhe": []}
+        n_miss = 0
+        for i in frames:
+            sums["ade"].append(sum(err[i, :(10 * n) // rs].mean() for n in (3, 5, 8)))
+            sums["fde"].append(err[i, 29 // rs] + err[i, 49 // rs] + err[i, -1])
+            sums["ahe"].append(sum(he[i, :(10 * n) // rs].mean() for n in (3, 5, 8)))
+            sums["fhe"].append(he[i, 29 // rs] + he[i, 49 // rs] + he[i, 79 // rs])
+            n_miss += int(any(err[i, :(10 * n) // rs].max() > th for n, th in ((3, 6), (5, 8), (8, 16))))
+        sc = {k: max(1 - float(np.mean(v)) / 3 / (8.0 if k in ("ade", "fde") else 0.8), 0) for k, v in sums.items()}
+        miss_score = 0 if n_miss >= 5 else 1
+        scores.append(miss_score * (sc["ade"] + sc["fde"] + 2 * sc["ahe"] + 2 * sc["fhe"]) / 6)
+        miss_scores.append(miss_score)
+    return float(np.average(scores)), float(np.average(miss_scores))

@@ -17,6 +17,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("ADX_TWO_TERM_ABLATION"):     # the two-term line needs the measurement library (python -m autodiffusion_amd.build --measure)
+    os.environ.setdefault("ADX_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "autodiffusion_amd", "libadx_measure.so"))
 from autodiffusion_amd import _lib, dit, metrics, synth  # noqa: E402
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 24

@@ -7,6 +7,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the ablation instances live in the measurement library only (python -m autodiffusion_amd.build --measure)
+os.environ.setdefault("ADX_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "autodiffusion_amd", "libadx_measure.so"))
 from autodiffusion_amd import ops, _lib  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -332,6 +332,56 @@ def test_metrics_host_formulas(golden):
             assert abs(a[k] - b[k]) < 1e-5 * max(1.0, abs(b[k])), (S, C, k, a[k], b[k])
 
 
+def test_product_library_has_no_ablation_instances():
+    """The kernel instances with parts switched off (wrong results on purpose) and the environment variables that select them
+    are compiled into the measurement library only; the product library does not even hold their names."""
+    from autodiffusion_amd import _lib
+    blob = open(os.path.join(os.path.dirname(_lib.__file__), "libadx.so"), "rb").read()
+    assert b"_ABLATE" not in blob
+
+
+def test_compute_scores_groups_frames_by_scenario():
+    """metrics.compute_scores (frames grouped by scenario15s_id, the clamp on the GROUP mean, five misses zero a group, the
+    combined score) against the loop restatement of utils/nuplan_utils.py:229-314 and against cases worked by hand.  Parity
+    unpinned: the reference module cannot be imported here."""
+    from autodiffusion_amd import metrics
+    from oracle import sampling
+    g = np.random.default_rng(21)
+    B = 57
+    label = np.cumsum(g.standard_normal((B, 80, 4)) * np.array([1.0, 0.2, 0.0, 0.02]), axis=1).astype(np.float32)
+    scale = g.choice([0.3, 2.0, 9.0], size=(B, 1, 1)) * np.array([1.0, 0.5, 0.0, 0.3])
+    pred = (label + g.standard_normal((B, 80, 4)) * scale).astype(np.float32)
+    ids = g.integers(0, 6, size=B) * 1000003 + 17          # six groups, uneven sizes, ids far apart, some groups with >= 5 misses
+    a = metrics.compute_metrics(torch.from_numpy(pred), torch.from_numpy(label), scenario15s_id=torch.from_numpy(ids))
+    ref = sampling.evaluation_scores(pred.astype(np.float64), label.astype(np.float64), ids)
+    assert 0.0 < ref[1] < 1.0                              # the case has zeroed and surviving groups
+    assert abs(a["average_score"] - ref[0]) < 1e-6 and abs(a["miss_score"] - ref[1]) < 1e-12
+    # by hand: one group of two frames, constant offsets of 2 m and 6 m in x, no heading error, no miss:
+    # ade = fde = 1 - ((2 + 6) / 2) / 8 = 0.5, heading scores 1 -> (0.5 + 0.5 + 2 + 2) / 6
+    lab = torch.zeros(2, 80, 4)
+    prd = lab.clone()
+    prd[0, :, 0], prd[1, :, 0] = 2.0, 5.9
+    s, m = metrics.compute_scores(metrics.per_scenario(prd, lab), [4, 4])
+    assert abs(s - (2 * (1 - (2.0 + 5.9) / 2 / 8) + 4) / 6) < 1e-6 and m == 1.0
+    # clamp on the group mean, not per frame: offsets 1 m and 17 m in ONE group give max(1 - 9/8, 0) = 0 (per-frame clamping
+    # would give 0.4375); as two groups the first keeps 0.875 and the second is a miss-free zero
+    prd[0, :, 0], prd[1, :, 0] = 1.0, 17.0
+    t = metrics.per_scenario(prd, lab)
+    t[:, 15:] = 0                                          # no misses, to isolate the displacement scores
+    s1, _ = metrics.compute_scores(t, [9, 9])
+    s2, _ = metrics.compute_scores(t, [9, 10])
+    assert abs(s1 - 4 / 6) < 1e-6 and abs(s2 - ((2 * 0.875 + 4) / 6 + 4 / 6) / 2) < 1e-6
+    # five missed frames zero their group's score whatever the errors of its other frames
+    lab6, prd6 = torch.zeros(6, 80, 4), torch.zeros(6, 80, 4)
+    prd6[:5, 10, 1] = 7.0                                  # 7 m at 1 s > the 6 m threshold of the 3 s horizon
+    s, m = metrics.compute_scores(metrics.per_scenario(prd6, lab6), [1] * 6)
+    assert s == 0.0 and m == 0.0
+    s, m = metrics.compute_scores(metrics.per_scenario(prd6[1:], lab6[1:]), [1] * 5)     # four misses: the group survives
+    assert s > 0.9 and m == 1.0
+    with pytest.raises(ValueError):
+        metrics.compute_scores(metrics.per_scenario(prd6, lab6), [1, 2])
+
+
 def test_mlp256_rejects_mismatched_operands():
     """The Python wrapper of the fused MLP derives the hidden width from the weight buffers' BYTE size and refuses operands that do
     not fit it (a wrong width would send the kernel's weight copies out of bounds)."""
