@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADX_LIB_PATH") or os.path.join(_HERE, "libadx.so")      # ADX_LIB_PATH: another build of the library (same-box A/B timings)
 
-ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY, ACT_SILU = range(6)
+ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY, ACT_SILU, ACT_TANH = range(7)     # ACT_TANH: adx_op_act only
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 VARIANT_A, VARIANT_DIT, VARIANT_MMDIT = 0, 1, 2
@@ -32,6 +32,7 @@ EXPORTS = [
     "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes",
     "adx_op_add", "adx_op_mul", "adx_op_act", "adx_op_act_bwd", "adx_op_group_colsum", "adx_op_transpose", "adx_op_gelu", "adx_op_gelu_bwd", "adx_reduce_ws_bytes", "adx_op_linear_wgrad", "adx_op_colsum",
     "adx_op_layernorm_bwd", "adx_op_attention_bwd", "adx_op_attention_stats", "adx_op_weighted_mse_bwd",
+    "adx_op_raster_patches",
 ]
 
 
@@ -121,6 +122,7 @@ def load() -> C.CDLL:
         "adx_op_attention_bwd": ([p, p, p, p, p, i, i, i, i, i, f, i, p, p, p, p, i, p], i),
         "adx_op_attention_stats": ([p, p, p, p, p, i, i, i, i, i, f, i, p], i),
         "adx_op_weighted_mse_bwd": ([p, p, p, p, p, p, i, i, p], i),
+        "adx_op_raster_patches": ([p, i, i, i, i, i, i, p, p], i),
     }
     for name, (args, res) in protos.items():
         fn = getattr(lib, name)

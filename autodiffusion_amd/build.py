@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libadx.so")
 OBJ = os.path.join(HERE, "csrc", "build")
-SOURCES = ["kernels.hip", "gemm.hip", "attn_mfma.hip", "modes.hip", "metrics.hip", "extras.hip", "fused_a.hip", "tail_a.hip", "tail_mfma.hip", "engine_base.hip", "engine_a.hip", "engine_dit.hip", "noalloc.hip", "backward.hip"]
+SOURCES = ["kernels.hip", "gemm.hip", "attn_mfma.hip", "modes.hip", "metrics.hip", "extras.hip", "fused_a.hip", "tail_a.hip", "tail_mfma.hip", "engine_base.hip", "engine_a.hip", "engine_dit.hip", "noalloc.hip", "backward.hip", "raster.hip"]
 HEADERS = ["adx_ops.h", "fastmath.h", "engine.h", os.path.join("..", "..", "include", "adx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

@@ -64,6 +64,7 @@ __device__ __forceinline__ float act_value(float v, int act) {
         case ADX_ACT_GELU_TANH: { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); return 0.5f * v * (1.0f + tanhf(u)); }
         case ADX_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
         case ADX_ACT_SILU: return v / (1.0f + expf(-v));
+        case ADX_ACT_TANH: return tanhf(v);
         default: return v;
     }
 }
@@ -77,6 +78,7 @@ __device__ __forceinline__ float act_slope(float v, int act) {
         }
         case ADX_ACT_LEAKY: return v > 0.f ? 1.0f : 0.01f;
         case ADX_ACT_SILU: { const float sg = 1.0f / (1.0f + expf(-v)); return sg * (1.0f + v * (1.0f - sg)); }
+        case ADX_ACT_TANH: { const float th = tanhf(v); return 1.0f - th * th; }
         default: return 1.0f;
     }
 }
@@ -740,14 +742,14 @@ ADX_API int adx_op_mul(const float* a, const float* b, float* out, int64_t n, vo
 
 ADX_API int adx_op_act(const float* x, float* y, int64_t n, int act, void* stream) {
     if (!x || !y || n <= 0) return fail(ADX_EINVAL, "act: null pointer or empty shape");
-    if (act < ADX_ACT_NONE || act > ADX_ACT_SILU) return fail(ADX_EINVAL, "act: unknown activation code");
+    if (act < ADX_ACT_NONE || act > ADX_ACT_TANH) return fail(ADX_EINVAL, "act: unknown activation code");
     hipLaunchKernelGGL(act_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, act);
     return done(hipGetLastError(), "act");
 }
 
 ADX_API int adx_op_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream) {
     if (!x || !dy || !dx || n <= 0) return fail(ADX_EINVAL, "act_bwd: null pointer or empty shape");
-    if (act < ADX_ACT_NONE || act > ADX_ACT_SILU) return fail(ADX_EINVAL, "act_bwd: unknown activation code");
+    if (act < ADX_ACT_NONE || act > ADX_ACT_TANH) return fail(ADX_EINVAL, "act_bwd: unknown activation code");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, act);
     return done(hipGetLastError(), "act_bwd");
 }

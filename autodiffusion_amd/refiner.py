@@ -9,9 +9,12 @@ Interfaces mirrored (paths relative to the reference tree):
 
 Parameter and buffer names are the reference's, so a reference ``state_dict`` loads
 with ``load_state_dict``.  The modules only *hold* parameters; every forward runs in
-the HIP engine.  Sampling (eval mode) and the forward-only evaluation of the training
-loss (what the HF-Trainer evaluation entry computes before it samples,
-transformer4planning/trainer.py:643) are implemented; gradients are not.
+the HIP engine.  Implemented: sampling (eval mode); the forward-only evaluation of the
+training loss (what the HF-Trainer evaluation entry computes before it samples,
+transformer4planning/trainer.py:643); and, whenever gradients are enabled and a parameter
+requires them, the differentiable training path of ``train.py`` (fp32; the chunks of a
+trajectory run as one batch whose map embedding is computed once per scenario), so
+``loss.backward()`` and any torch optimizer work on these classes.
 
 Deviations, all deliberate:
 * ``Transformer.forward`` returns ``(B, T, C)`` always (the reference's trailing
@@ -22,9 +25,11 @@ Deviations, all deliberate:
   reproducible and shard-invariant; without it, noise is drawn on the device inside
   the captured graph (counter-based generator keyed by ``seed`` and the global batch
   row ``row0 + b``; ``seed=None`` takes a fresh seed from torch's CPU generator).
-* the loss is evaluated without dropout (the reference leaves its refiner in train
-  mode inside ``forward``, DiffusionAugmentation.py:109, so its evaluation loss is a
-  dropout sample; this is the dropout-free value) and takes optional ``t`` / ``noise``.
+* the loss -- evaluated or trained -- has no dropout (the reference leaves its refiner in
+  train mode inside ``forward``, DiffusionAugmentation.py:109, so its loss is a dropout
+  sample with p = 0.1; here it is the dropout-free value, i.e. the reference with its
+  denoiser in ``.eval()``); the training path warns once about it.  ``forward`` takes
+  optional ``t`` / ``noise``.
 """
 from __future__ import annotations
 
@@ -118,7 +123,7 @@ class SinusoidalPosEmb(nn.Module):
 
 
 class Transformer(nn.Module):
-    """Encoder/decoder denoiser.  Constructor arguments as in the reference; ``precision`` ("fp32" | "bf16")
+    """Encoder/decoder denoiser.  Constructor arguments as in the reference; ``precision`` ("fp32" | "bf16" | "bf16x3")
     and ``elide`` (skip mask-unobservable work) select the engine build."""
 
     def __init__(self, input_dim: int, output_dim: int, horizon: int, n_cond_steps: int = None, cond_dim: int = 0,
@@ -160,6 +165,7 @@ class Transformer(nn.Module):
             raise NotImplementedError("n_prior_steps must equal horizon")
         self.precision = precision
         self.elide = int(elide)
+        self.p_drop_emb, self.p_drop_attn = float(p_drop_emb), float(p_drop_attn)      # recorded; no kernel applies them
         self._n_head = int(n_head)
         self._engine: Optional[Engine] = None
         self._engine_key = None

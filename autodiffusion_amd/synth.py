@@ -162,6 +162,12 @@ def hidden_state(batch: int, n_embd: int, seed: int = 7, row0: int = 0, points: 
     return torch.from_numpy(_rows(seed, "state", row0, batch, (points, n_embd)))
 
 
+def occupancy_raster(batch: int, channels: int, seed: int = 7, size: int = 224, density: float = 0.08) -> torch.Tensor:
+    """Rasterised nuPlan-style inputs ``(B, 224, 224, C)``, channels last: sparse 0 / 1 occupancy, ``density`` of the pixels set."""
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.random((batch, size, size, channels)) < density).astype(np.float32))
+
+
 def noise(batch: int, lead: Tuple[int, ...], tail: Tuple[int, ...], seed: int = 1234, row0: int = 0) -> torch.Tensor:
     """Gaussian noise ``lead + (B,) + tail`` where batch row r depends only on its global index.
 

@@ -366,8 +366,24 @@ def trainable_names(module: torch.nn.Module) -> List[str]:
     return [n for n, _ in module.named_parameters()]
 
 
+_warned_dropout = False
+
+
+def warn_no_dropout(module: torch.nn.Module) -> None:
+    """The reference trains with nn.Dropout(p) active (transformer.py:52,70-98; torch's TransformerEncoderLayer default 0.1 inside
+    every DiT block); this path applies none.  Say so once per process when a module in training mode asks for gradients."""
+    global _warned_dropout
+    p = max(float(getattr(module, "p_drop_emb", 0.1)), float(getattr(module, "p_drop_attn", 0.1)))
+    if module.training and p > 0 and not _warned_dropout:
+        import warnings
+        warnings.warn(f"autodiffusion_amd trains without dropout: the module is in training mode and its configured dropout is {p}, "
+                      "but no kernel applies it -- loss and gradients are those of the reference with its denoiser in .eval()", stacklevel=3)
+        _warned_dropout = True
+
+
 def denoise_with_grad(module: torch.nn.Module, x, t, condition: Dict[str, torch.Tensor], n_head: int, maps_repeat: int = 1) -> torch.Tensor:
     """Differentiable call of a ``refiner.Transformer``: the result carries a grad_fn whose backward fills the module's ``.grad``s."""
+    warn_no_dropout(module)
     names = trainable_names(module)
     params = [p for _, p in module.named_parameters()]
     n_enc, n_dec = len(module.encoder.layers), len(module.decoder.layers)
@@ -663,6 +679,8 @@ class DenoiserDiT(torch.autograd.Function):
 
 def denoise_dit_with_grad(module: torch.nn.Module, x, t, state) -> torch.Tensor:
     """Differentiable call of a ``dit.Transformer_TrajDiffusionModel`` (DiT or MM-DiT backbone)."""
+    if module.config.diffusion_backbone == "DiT":          # MM-DiT blocks hold no dropout layer
+        warn_no_dropout(module)
     named = [(n, p) for n, p in module.named_parameters()]
     meta = (tuple(n for n, _ in named), int(module.config.n_head), len(module.blocks), len(list(module.state_encoder.children())),
             len(list(module.x_encoder.children())), module.config.diffusion_backbone == "MM-DiT")

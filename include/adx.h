@@ -29,7 +29,8 @@ extern "C" {
 
 enum { ADX_OK = 0, ADX_EINVAL = 1, ADX_ESTATE = 2, ADX_EHIP = 3, ADX_ENOMEM = 4, ADX_ENOTFOUND = 5 };
 
-enum { ADX_ACT_NONE = 0, ADX_ACT_RELU = 1, ADX_ACT_GELU_ERF = 2, ADX_ACT_GELU_TANH = 3, ADX_ACT_LEAKY = 4, ADX_ACT_SILU = 5 };
+enum { ADX_ACT_NONE = 0, ADX_ACT_RELU = 1, ADX_ACT_GELU_ERF = 2, ADX_ACT_GELU_TANH = 3, ADX_ACT_LEAKY = 4, ADX_ACT_SILU = 5,
+       ADX_ACT_TANH = 6 /* stand-alone operator adx_op_act only (action / key-point embeddings of the raster encoder) */ };
 /* GEMM operand type; accumulation is always f32.  BF16X3 (engines only): bf16 MFMA on operands split into
  * high + low bf16 halves (x_lo w_hi + x_hi w_lo + x_hi w_hi), ~16 mantissa bits per operand. */
 enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1, ADX_PREC_BF16X3 = 2 };
@@ -221,6 +222,17 @@ int adx_op_q_sample(const float* x0, const float* noise, const int64_t* t, const
  * loss_mean[0] (nullable) = mean over rows. */
 int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows,
                         float* loss_mean, int n_rows, int row_len, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Conditioning producer, first stage (phase 1 of generate(): NuplanRasterizeEncoder.forward,
+ * models/encoder/nuplan_raster_encoder.py:178-187, with cat_raster_seq, models/utils.py:14-41, and the Conv2d patch embedding
+ * of the ViT it feeds).  raster[B][H][W][C] is the channels-last raster as the data loader hands it over, C = route + 20 road +
+ * 4 traffic-light + 8 agent channels per context frame (agent channel a of frame f at route + 24 + f + a * framenum).
+ * out[(b * framenum + f) * (W/16) * (H/16) + py * (H/16) + px][(c * 16 + ky) * 16 + kx] = raster[b][px*16 + kx][py*16 + ky][chan(c, f)]
+ * with c over the route + 20 (+ 4 when `traffic`) shared channels followed by frame f's 8 agent channels: the rows of the patch
+ * matrix whose product with the flattened Conv2d filter [hidden][c * 256] (adx_op_linear) is the reference's patch embedding of
+ * raster.permute(0, 3, 2, 1) split into frames.  H, W multiples of 16; C <= 149. */
+int adx_op_raster_patches(const float* raster, int B, int H, int W, int C, int framenum, int traffic, float* out, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Operators of the training paths (fp32): the refiner, the flattened wrapper and the decoder twin.  The reference differentiates

@@ -620,8 +620,63 @@ def g17_c5_loop():
 
 C5_READOUT, C5_GATE = 0.93, 0.1
 
+
+# ----------------------------------------------------------------------------- G18: conditioning producer, first stage (ViT raster encoder)
+def vit_checkpoint_name(name: str) -> str:
+    """Parameter name of the installed transformers' ViTModel -> the name the same tensor has in a reference checkpoint
+    (transformers 4.42.3, the version the reference pins): the seeded weights are keyed by the latter."""
+    import re
+    m = re.match(r"(.*)layers\.(\d+)\.(.*)", name)
+    if not m:
+        return name
+    pre, i, rest = m.groups()
+    table = {"attention.q_proj": "attention.attention.query", "attention.k_proj": "attention.attention.key",
+             "attention.v_proj": "attention.attention.value", "attention.o_proj": "attention.output.dense",
+             "mlp.fc1": "intermediate.dense", "mlp.fc2": "output.dense"}
+    for k, v in table.items():
+        if rest.startswith(k + "."):
+            rest = v + rest[len(k):]
+            break
+    return f"{pre}encoder.layer.{i}.{rest}"
+
+
+def g18_raster_encoder():
+    """NuplanRasterizeEncoder.forward of the reference (ViT branch): rasters + context actions -> (input_embeds, info_dict,
+    maps_info).  Two sizes: a small ViT (n_embd 64 -> hidden 32, 4 heads, intermediate 96) stored whole (input_embeds = maps_info
+    followed by the stored tail), with key points
+    ('specified_backward'); and the mixtral-small configuration (n_embd 256 -> hidden 128, 8 heads, intermediate 3072, no key points)
+    stored as every 7th token.  4 context frames, 34 raster channels per frame (58 in the raster), is_training False."""
+    from transformer4planning.models.encoder.nuplan_raster_encoder import NuplanRasterizeEncoder
+    out = {}
+    for tag, n_embd, n_head, inter, kp, B in (("small", 64, 4, 96, "specified_backward", 2), ("full", 256, 8, 3072, "no", 1)):
+        cfg = SimpleNamespace(use_proposal=0, use_key_points=kp, n_embd=n_embd, raster_encoder_type="vit", raster_channels=34,
+                              vit_intermediate_size=inter, n_head=n_head, use_speed=False, separate_kp_encoder=True,
+                              camera_image_encoder=None, x_random_walk=0.0, y_random_walk=0.0, arf_x_random_walk=0.0, arf_y_random_walk=0.0,
+                              with_traffic_light=True, autoregressive_proposals=False)
+        enc = NuplanRasterizeEncoder(cfg)
+        with torch.no_grad():
+            for n, p in enc.named_parameters():
+                p.copy_(synth.seeded_param(vit_checkpoint_name(n), tuple(p.shape), WSEED))
+        enc.eval()
+        high, low = synth.occupancy_raster(B, 58, ISEED), synth.occupancy_raster(B, 58, ISEED + 1)
+        actions = synth.noise(B, (), (4, 4), NSEED + 7) * torch.tensor([2.0, 0.3, 0.0, 0.1])
+        label = synth.trajectory_prior(B, ISEED)
+        with torch.no_grad():
+            embeds, info, maps = enc(high_res_raster=high, low_res_raster=low, context_actions=actions, trajectory_label=label,
+                                     is_training=False)
+        assert maps.shape == (B, 788, n_embd), maps.shape
+        out[f"{tag}_context_actions"] = actions
+        if tag == "small":
+            assert torch.equal(embeds[:, :788], maps)
+            out["small_maps_info"], out["small_input_embeds_tail"] = maps, embeds[:, 788:]       # key-point tokens + zero rows
+        else:
+            out["full_maps_info_every7"] = maps[:, ::7]
+            out["full_input_embeds_shape"] = np.array(embeds.shape)
+        print(f"g18 {tag}: maps_info rms {float(maps.pow(2).mean().sqrt()):.3f}, input_embeds {tuple(embeds.shape)}, context_length {info['context_length']}")
+    save("g18_raster_encoder", **out)
+
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
-       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop}
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop, "g18": g18_raster_encoder}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

@@ -529,3 +529,44 @@ def test_philox_generator_statistics():
     # a shard that starts at global row 20 draws what rows 20.. of the full batch draw
     np.testing.assert_array_equal(sampling.philox_randn(3, 10, 400, seed=99, row0=25), z[:, 20:30])
     assert not np.array_equal(sampling.philox_randn(1, 4, 8, seed=1), sampling.philox_randn(1, 4, 8, seed=2))
+
+
+# ------------------------------------------------------------------ G18: conditioning producer, first stage (ViT raster encoder)
+def raster_encoder_sd(n_embd, n_head, inter, key_points, n_layer=12, channels=34):
+    """Seeded weights of the raster encoder under the parameter names of a reference checkpoint."""
+    h = n_embd // 2
+    shapes = [("image_downsample.embeddings.cls_token", (1, 1, h)), ("image_downsample.embeddings.position_embeddings", (1, 197, h)),
+              ("image_downsample.embeddings.patch_embeddings.projection.weight", (h, channels, 16, 16)),
+              ("image_downsample.embeddings.patch_embeddings.projection.bias", (h,)),
+              ("image_downsample.layernorm.weight", (h,)), ("image_downsample.layernorm.bias", (h,)),
+              ("action_m_embed.0.weight", (n_embd, 4)), ("action_m_embed.0.bias", (n_embd,))]
+    if key_points:
+        shapes += [("kps_m_embed.0.weight", (n_embd, 2)), ("kps_m_embed.0.bias", (n_embd,))]
+    for i in range(n_layer):
+        p = f"image_downsample.encoder.layer.{i}."
+        for n in ("attention.attention.query", "attention.attention.key", "attention.attention.value", "attention.output.dense"):
+            shapes += [(p + n + ".weight", (h, h)), (p + n + ".bias", (h,))]
+        shapes += [(p + "intermediate.dense.weight", (inter, h)), (p + "intermediate.dense.bias", (inter,)),
+                   (p + "output.dense.weight", (h, inter)), (p + "output.dense.bias", (h,))]
+        for n in ("layernorm_before", "layernorm_after"):
+            shapes += [(p + n + ".weight", (h,)), (p + n + ".bias", (h,))]
+    return synth.seeded_state(shapes, WSEED)
+
+
+def test_raster_encoder(golden):
+    from oracle import raster
+    g = golden("g18_raster_encoder")
+    sd = raster_encoder_sd(64, 4, 96, True)
+    high, low = synth.occupancy_raster(2, 58, ISEED), synth.occupancy_raster(2, 58, ISEED + 1)
+    label = synth.trajectory_prior(2, ISEED)
+    embeds, maps = raster.encoder_forward(sd, high, low, T(g["small_context_actions"]), label, 4, [79, 39, 19, 9, 4])
+    assert rel_err(maps, g["small_maps_info"]) < 1e-4
+    assert rel_err(embeds[:, 788:], g["small_input_embeds_tail"]) < 1e-5 and torch.equal(embeds[:, :788], maps)
+    # cat_raster_seq: frame f's image = the shared channels + agent channels route + 24 + f + a * framenum
+    r = torch.arange(58, dtype=torch.float32).reshape(1, 58, 1, 1)
+    seq = raster.cat_raster_seq(r, 4)
+    assert seq.shape == (1, 4, 34, 1, 1)
+    assert seq[0, 2, :, 0, 0].tolist() == list(range(26)) + [26 + 2 + 4 * a for a in range(8)]
+    sd = raster_encoder_sd(256, 8, 3072, False)
+    maps = raster.raster_maps_info(sd, synth.occupancy_raster(1, 58, ISEED), synth.occupancy_raster(1, 58, ISEED + 1), T(g["full_context_actions"]), 8)
+    assert rel_err(maps[:, ::7], g["full_maps_info_every7"]) < 1e-4
