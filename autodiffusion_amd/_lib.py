@@ -29,7 +29,7 @@ EXPORTS = [
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
     "adx_generate_a", "adx_sample_dit", "adx_sample_dit_grouped", "adx_debug_stage_a", "adx_op_select_modes", "adx_op_trajectory_metrics", "adx_engine_profile", "adx_engine_profile_read",
     "adx_engine_set_noise_seed", "adx_op_randn", "adx_engine_capture_count", "adx_op_q_sample", "adx_op_weighted_mse",
-    "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes",
+    "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes", "adx_noalloc_init",
     "adx_op_add", "adx_op_mul", "adx_op_act", "adx_op_act_bwd", "adx_op_group_colsum", "adx_op_transpose", "adx_op_gelu", "adx_op_gelu_bwd", "adx_reduce_ws_bytes", "adx_op_linear_wgrad", "adx_op_colsum",
     "adx_op_layernorm_bwd", "adx_op_attention_bwd", "adx_op_attention_stats", "adx_op_weighted_mse_bwd",
     "adx_op_raster_patches",
@@ -105,6 +105,7 @@ def load() -> C.CDLL:
         "adx_engine_capture_count": ([p], i64),
         "adx_op_linear_noalloc": ([p, p, p, p, i, i, i, i, i, p], i),
         "adx_noalloc_scratch_bytes": ([], C.c_size_t),
+        "adx_noalloc_init": ([], i),
         "adx_op_q_sample": ([p, p, p, p, p, p, p, i, i, p], i),
         "adx_op_weighted_mse": ([p, p, p, p, p, p, i, i, p], i),
         "adx_op_add": ([p, p, p, i64, p], i),

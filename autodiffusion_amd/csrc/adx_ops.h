@@ -55,6 +55,7 @@ bool linear_planes_ok(int M, int N, int K, int prec);
 // x[M][K] (row stride ldx, optional SiLU) -> K-blocked planes [K/16][M][16]: hi = bf16(x), lo (nullable) = bf16(x - hi).
 hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream);
 size_t linear_stage_bytes(int M, int N, int K, int prec);
+hipError_t linear_staged_prepare();          // one-time, non-stream set-up of the staged product's kernels (call outside graph capture)
 hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream);   // [N][K] bf16 -> [K/16][N][16]
 hipError_t linear(const LinearArgs& a, hipStream_t stream);        // picks linear_big when linear_big_ok(a)
 // Two products in one kernel, the hidden layer kept on the chip: Y = epilogue2(act1(X W1^T + b1) W2^T + b2) for K = 256 inputs and

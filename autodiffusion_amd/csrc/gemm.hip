@@ -11,6 +11,8 @@
 // Split-operand mode (PREC_BF16X3): x = x_hi + x_lo, w = w_hi + w_lo, three MFMAs per product (x_lo w_hi, x_hi w_lo,
 // x_hi w_hi).  A row's result depends only on that row of X, so outputs do not depend on how the batch is sharded.
 #include "adx_ops.h"
+
+#include <mutex>
 #include "fastmath.h"
 
 #include <math.h>
@@ -1037,6 +1039,20 @@ __global__ __launch_bounds__(256) void stage_w_kernel(const unsigned short* __re
     *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(w + (int64_t)n * K + kb * 16 + c * 8);
 }
 
+// hipFuncSetAttribute once per kernel instance and process (it is not a stream operation: a launch recorded during graph capture
+// must not depend on it, see linear_staged_prepare).
+static hipError_t ensure_dynamic_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static const void* done[64];
+    static int n_done = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_done; ++i)
+        if (done[i] == fn) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && n_done < 64) done[n_done++] = fn;
+    return e;
+}
+
 template <bool X3>
 static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
     constexpr size_t smem = (X3 ? 4 : 8) * (X3 ? 4 : 2) * (size_t)GIMG_B;      // ring of K-step buffers: 128 KB
@@ -1056,7 +1072,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
 #else
     constexpr int abl = 0;
 #endif
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return hipErrorInvalidValue;
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)smem) != hipSuccess) return hipErrorInvalidValue;
     const size_t xe = a.Xh ? 0 : (size_t)a.M * a.K, we = (size_t)a.N * a.K;          // scratch layout: [X planes unless given][W planes unless given]
     unsigned short* base = reinterpret_cast<unsigned short*>(a.xstage);
     StagedOperands so;
@@ -1113,8 +1129,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
             if (abl == 0 && ks == 2) kern2 = &linear_glds2_kernel<false, 16, 2>;
             if (abl == 0 && ks == 3) kern2 = &linear_glds2_kernel<false, 16, 3>;
         }
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2) != hipSuccess)
-            return hipErrorInvalidValue;
+        if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern2), (int)smem2) != hipSuccess) return hipErrorInvalidValue;
         const int tiles_m = (a.M + G2_TM - 1) / G2_TM, tiles_n = (a.N + G2_TN - 1) / G2_TN;
         const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
         const int blocks = (int)((n_tiles + 7) / 8) * 8;
@@ -1620,6 +1635,15 @@ static hipError_t launch_big(const LinearArgs& a, hipStream_t stream) {
     return a.in_act == ACT_SILU ? launch_big2<X3, WM, true>(a, stream) : launch_big2<X3, WM, false>(a, stream);
 }
 
+// Everything the staged product needs that is not a stream operation (the dynamic-LDS attribute of its kernels), so that a later
+// call can run while its stream is being captured into a graph.
+hipError_t linear_staged_prepare() {
+    constexpr int smem_x3 = 3 * 2 * (G2_A_B + G2_B_B), smem_1 = 6 * (G2_A_B + G2_B_B);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_glds2_kernel<true, 16>), smem_x3);
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_glds2_kernel<false, 16>), smem_1);
+    return e;
+}
+
 size_t linear_stage_bytes(int M, int N, int K, int prec) { return ((size_t)M + N) * K * 2 * (prec == PREC_BF16X3 ? 2 : 1); }
 
 bool linear_planes_ok(int M, int N, int K, int prec) {
@@ -1693,7 +1717,8 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
         if (!stage_fits || !linear_planes_ok(a.M, a.N, a.K, a.prec) || (a.prec == PREC_BF16X3 && !a.Xl) || a.xmap.per_batch != 0) return hipErrorInvalidValue;
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);
     }
-    if (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any || a.force_staged) && stage_fits &&
+    // force_staged (the allocation-free entry point) overrides the tuning switches: that entry point promises this kernel
+    if ((a.force_staged || (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any))) && stage_fits &&
         (a.xstage || stage_need == 0) &&
         (int64_t)a.M * a.K < ((int64_t)1 << 31) && (int64_t)a.N * a.K < ((int64_t)1 << 31))
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);

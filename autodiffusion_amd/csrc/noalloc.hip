@@ -45,6 +45,17 @@ int scratch_on_current_device(void** out) {
 
 ADX_API size_t adx_noalloc_scratch_bytes(void) { return ADX_NOALLOC_SCRATCH_BYTES; }
 
+// Per-device set-up of adx_op_linear_noalloc, to be called once with the device current and with NO stream capture in
+// progress: looks up the fixed array's address on this device (the first lookup loads the library's code object) and sets the
+// staged kernels' attributes.  adx_op_linear_noalloc does the same on its first call on a device, so a caller that never
+// captures may skip this; a caller that captures must call it (or make one eager call) first.
+ADX_API int adx_noalloc_init(void) {
+    void* ptr = nullptr;
+    ADX_TRY(scratch_on_current_device(&ptr));
+    const hipError_t e = linear_staged_prepare();
+    return e == hipSuccess ? ADX_OK : hip_fail(e, "noalloc_init");
+}
+
 ADX_API int adx_op_linear_noalloc(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act, int prec,
                                   void* stream) {
     if (!x || !w || !y) { set_error("linear_noalloc: null pointer"); return ADX_EINVAL; }

@@ -218,7 +218,7 @@ class DiffusionWrapper(nn.Module):
         parameters the denoiser call is the differentiable training path (``train.py``, both backbones; gradients also reach
         ``hidden_state`` when it requires them); under ``torch.no_grad()`` only the value."""
         from . import train
-        grad = train.wants_grad(self.model)
+        grad = train.wants_grad(self.model, hidden_state)
         if grad:
             return self._train_forward(hidden_state, trajectory_label, info_dict, t, noise, True)
         with torch.no_grad():

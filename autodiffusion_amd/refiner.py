@@ -273,7 +273,7 @@ class DiffusionWrapper(nn.Module):
         fills the denoiser's ``.grad``s as the reference's autograd does; otherwise (``torch.no_grad()``, the evaluation
         entry) only the value is computed, on the sampling engine."""
         from . import train
-        if train.wants_grad(self.model):
+        if train.wants_grad(self.model, prior.get("transition_info")):
             return self._p_losses_grad(prior, x_start, t, noise, return_rows)
         with torch.no_grad():
             return self._p_losses_value(prior, x_start, t, noise, return_rows)
@@ -436,7 +436,7 @@ class DiffusionAugmentation(nn.Module):
         label = _lib.f32c(trajectory_label).reshape(B, n_chunks, fs, -1)
         prior = _lib.f32c(trajectory_prior).reshape(B, n_chunks, fs, -1)
         from . import train
-        if train.wants_grad(self.diffusion.diffusion.model):
+        if train.wants_grad(self.diffusion.diffusion.model, self.init_x):
             # Training: the chunks do not depend on each other here (every chunk after the first sees a zero transition), so
             # they run as ONE batch of n_chunks * B rows (row = chunk * B + scenario) that shares the scenarios' map tokens.
             C = label.shape[-1]

@@ -334,6 +334,10 @@ class DenoiserA(torch.autograd.Function):
         out, tape = denoiser_forward(P, f32c(x), t, f32c(maps) if maps is not None else None, f32c(transition), f32c(prior), n_head, n_enc, n_dec,
                                      maps_repeat)
         ctx.meta, ctx.P, ctx.tape = meta, P, tape
+        for i, what in ((1, "x"), (3, "maps_info"), (5, "trajectory_prior")):
+            if ctx.needs_input_grad[i]:       # the reference's autograd would propagate; this path does not produce these gradients
+                raise NotImplementedError(f"the training path computes no gradient for the input `{what}` (it requires grad): detach it, "
+                                          "or differentiate the producer of that tensor separately")
         ctx.want_tr = bool(ctx.needs_input_grad[4])
         return out
 
@@ -391,8 +395,13 @@ def denoise_with_grad(module: torch.nn.Module, x, t, condition: Dict[str, torch.
     return DenoiserA.apply((tuple(names), n_head, n_enc, n_dec, int(maps_repeat)), x, t, maps, condition["transition_info"], condition["trajectory_prior"], *params)
 
 
-def wants_grad(module: torch.nn.Module) -> bool:
-    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+def wants_grad(module: torch.nn.Module, *inputs) -> bool:
+    """Take the differentiable path?  Gradients enabled and something to train: a parameter of ``module``, or one of ``inputs``
+    (tensors that enter the denoiser differentiably -- the learnable initial transition, a backbone state -- and may be the only
+    trainable thing when the denoiser itself is frozen)."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(p.requires_grad for p in module.parameters()) or any(torch.is_tensor(v) and v.requires_grad for v in inputs)
 
 
 # ================================================================================================ decoder twin (DiT backbone)
@@ -565,11 +574,18 @@ def _mm_block(P, prefix: str, x, c, silu_y, n_head: int):
 
 
 def _mm_block_bwd(P, G, prefix: str, saved, silu_y, dx_out, dc_out, n_head: int):
+    """``dc_out`` None: the block's condition-stream output is unused (the last block).  Its linear_c / mlp_c and the gate, shift
+    and scale rows 2..5 of adaLN_modulation_c then take no part in the loss: their stream backward is skipped and they get zero
+    rows (adaLN) or no gradient at all (linear_c, mlp_c: None, as torch's autograd leaves them)."""
     x, c, mx, mc, xh, ch, q, k, v, o, stats, scale, op, sx, sc = saved
     dx, dop_x, gx = _mm_stream_bwd(P, G, prefix, "x", mx, op, sx, dx_out)
-    dc, dop_c, gc = _mm_stream_bwd(P, G, prefix, "c", mc, op, sc, dc_out)
+    if dc_out is None:
+        dc, dop, gc = None, dop_x, [None, None] + [torch.zeros_like(mc[i]) for i in range(2, 6)]
+    else:
+        dc, dop_c, gc = _mm_stream_bwd(P, G, prefix, "c", mc, op, sc, dc_out)
+        dop = add(dop_x, dop_c)
     a = prefix + "attn."
-    do = _lin_bwd(P, G, add(dop_x, dop_c), o, a + "proj.")
+    do = _lin_bwd(P, G, dop, o, a + "proj.")
     dq, dk, dv = attention_bwd(q, k, v, o, do, n_head, scale=scale, stats=stats)
     parts = {"q": _heads_split(dq, n_head), "k": _heads_split(dk, n_head), "v": _heads_split(dv, n_head)}
     dxh = add(add(_lin_bwd(P, G, parts["q"][0], xh, a + "Wq_x."), _lin_bwd(P, G, parts["k"][0], xh, a + "Wk_x.")),
@@ -580,7 +596,7 @@ def _mm_block_bwd(P, G, prefix: str, saved, silu_y, dx_out, dc_out, n_head: int)
     dc_mod, gc[0], gc[1] = _modulate_bwd(c, mc[1], dch)
     dsilu = add(_lin_bwd(P, G, torch.cat(gx, dim=-1), silu_y, prefix + "adaLN_modulation_x.1."),
                 _lin_bwd(P, G, torch.cat(gc, dim=-1), silu_y, prefix + "adaLN_modulation_c.1."))
-    return add(dx, dx_mod), add(dc, dc_mod), dsilu
+    return add(dx, dx_mod), (dc_mod if dc is None else add(dc, dc_mod)), dsilu
 
 
 def dit_forward(P: Dict[str, torch.Tensor], x, t, state, n_head: int, n_blocks: int, n_state: int, n_x: int, mm: bool = False):
@@ -630,9 +646,7 @@ def dit_backward(P: Dict[str, torch.Tensor], tape, dout, n_head: int, want_state
     dsilu = _lin_bwd(P, G, torch.cat([dsh, dsc], dim=-1), silu_c, "final_layer.adaLN_modulation.1.")
     dcs = None                                                      # MM-DiT: gradient of the condition stream
     for i in reversed(range(len(tape["blocks"]))):
-        if tape["mm"]:
-            if dcs is None:                                         # the last block's condition output is not used
-                dcs = torch.zeros_like(dh)
+        if tape["mm"]:                                              # dcs None: the last block's condition output is not used
             dh, dcs, ds_i = _mm_block_bwd(P, G, f"blocks.{i}.", tape["blocks"][i], silu_c, dh, dcs, n_head)
         else:
             dh, ds_i = _dit_block_bwd(P, G, f"blocks.{i}.", tape["blocks"][i], silu_c, dh, n_head)
@@ -664,6 +678,8 @@ class DenoiserDiT(torch.autograd.Function):
         P = {n: p.detach() for n, p in zip(names, params)}
         out, tape = dit_forward(P, f32c(x), t, f32c(state), n_head, n_blocks, n_state, n_x, mm)
         ctx.meta, ctx.P, ctx.tape = meta, P, tape
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("the training path computes no gradient for the input `x` (it requires grad): detach it")
         ctx.want_state = bool(ctx.needs_input_grad[3])
         return out
 

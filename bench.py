@@ -72,10 +72,28 @@ def time_kernel(fn, iters=20):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-# HBM bytes of one launch of the encoder row kernel at B = 1024 from the L2 fabric-request counters (separate rocprofv3
-# --pmc passes: TCC_EA0_RDREQ x 128 B -- i.e. FETCH_SIZE doubled, the gfx950 correction -- plus TCC_EA0_WRREQ x 64 B);
-# the per-row figure scales with B.  Source: profiles/r02_pmc_refiner.txt.
-ENC_ROWS_TRAFFIC_BYTES_PER_ROW = (1874131.7 * 128 + 1701898.4 * 64) / (1024 * L_COND)
+def pmc_counters(kernel_prefix="enc_rows_ke"):
+    """Per-launch hardware counters of one kernel from the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_refiner.txt,
+    collected at B = 1024 scenarios = 828 416 conditioning rows in separate passes per counter group).  Counter collection needs the
+    profiler, so this run reads the committed figures and scales them by the row count; the line names the file."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_refiner.txt")))
+    if not files:
+        return None, {}
+    out, cur = {}, None
+    for ln in open(files[-1]):
+        if ln.startswith("void "):
+            cur = ln
+            continue
+        m = re.match(r"\s+(\w+)\s+n=\s*\d+\s+avg=\s*([0-9.]+)", ln)
+        if m and cur and kernel_prefix in cur:
+            out[m.group(1)] = float(m.group(2))
+    return os.path.relpath(files[-1], ROOT), out
+
+
+PMC_ROWS = 1024 * 809           # conditioning rows of the launch the committed counters were collected on
+SIMDS, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMDs; peak engine clock
 def enc_rows_read_bytes_per_row(B, n_steps):
     """x0 (128) + the cached attention output o / l (128) + this step's gates (32) while the per-chunk gate table fits the
     engine's budget (its rule, ADX_GATE_TABLE_MAX_MB included); otherwise x0 + layer-0 query (128) + normalised state (160)."""
@@ -119,12 +137,29 @@ def roofline(da, B, step):
     rd = enc_rows_read_bytes_per_row(B, N_SAMPLE if N_SAMPLE < N_TRAIN else N_TRAIN)
     algo = float((rd + wr) * rows)
     achieved = algo / t["enc_rows"] / 1e9
-    return {"kernel": "enc_rows_kernel (encoder layer 0 after its attention + layer 1 LayerNorm over all conditioning rows)", "bound": "hbm",
+    line = {"kernel": "enc_rows_kernel (encoder layer 0 after its attention + layer 1 LayerNorm over all conditioning rows)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": round(ENC_ROWS_TRAFFIC_BYTES_PER_ROW * rows) if wr == 128 and rd == 288 and FS == 10 else None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
+            "traffic": None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
             "launches_timed": launches, "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()},
-            "note": "HBM is the binding one of the two roofs, but the kernel is limited by vector issue: with no HBM traffic at all "
-                    "(no stores, inputs from L2) it still takes 80 of its 96 us (profiles/r02_enc_rows_ablation.txt)"}
+            "note": "HBM is the binding one of the two roofs the contract offers, but the kernel is limited by vector issue (see `issue`): with "
+                    "no HBM traffic at all (no stores, inputs from L2) it still takes 80 of its 96 us (profiles/r02_enc_rows_ablation.txt)"}
+    src, pmc = pmc_counters()
+    same_form = wr == 128 and rd == 288 and FS == 10          # the kernel form the counters were collected on
+    if same_form and "TCC_EA0_RDREQ_sum" in pmc and "TCC_EA0_WRREQ_sum" in pmc:
+        # HBM bytes = read requests x 128 B (FETCH_SIZE doubled: the gfx950 correction) + write requests x 64 B, scaled by rows
+        line["traffic"] = round((pmc["TCC_EA0_RDREQ_sum"] * 128 + pmc["TCC_EA0_WRREQ_sum"] * 64) * rows / PMC_ROWS)
+        line["traffic_source"] = f"{src} (TCC_EA0_RDREQ x 128 B + TCC_EA0_WRREQ x 64 B per launch at B=1024, scaled by the row count; not collected in this run)"
+    if same_form and "SQ_INSTS_VALU" in pmc and "SQ_INSTS_MFMA" in pmc:
+        # The roof that binds.  A SIMD issues one vector instruction per 4 cycles and one 32x32x16 MFMA per 32 cycles, and in this
+        # kernel the two do not overlap: T >= (4 N_valu + 32 N_mfma) / (SIMDs x clock).
+        valu, mfma = pmc["SQ_INSTS_VALU"] * rows / PMC_ROWS, pmc["SQ_INSTS_MFMA"] * rows / PMC_ROWS
+        model_us = (4 * valu + 32 * mfma) / SIMDS / (CLOCK_GHZ * 1e3)
+        line["issue"] = {"valu_insts": round(valu), "mfma_insts": round(mfma), "model_us": round(model_us, 1),
+                         "frac": round(model_us / (t["enc_rows"] * 1e6), 4), "clock_ghz": CLOCK_GHZ, "simds": SIMDS,
+                         "model": "(4 cycles x vector instructions + 32 cycles x matrix instructions) / (SIMDs x clock): the time the kernel's own "
+                                  "instruction stream needs at full issue rate; frac = model_us / launch_us",
+                         "source": f"{src} (SQ_INSTS_VALU, SQ_INSTS_MFMA per launch at B=1024, scaled by the row count; not collected in this run)"}
+    return line
 
 
 # ------------------------------------------------------------------------------------------------ DiT decoder workloads
@@ -254,12 +289,36 @@ def cpu_baseline():
             dt1 = (time.perf_counter() - t0) / 10
         finally:
             torch.set_num_threads(threads)
-    return {"value": round(B / (dt * n_chunks), 4), "unit": "trajectories/s", "cores": threads, "kind": "port",
+    dit_row = cpu_baseline_dit()
+    return {"dit256": dit_row, "value": round(B / (dt * n_chunks), 4), "unit": "trajectories/s", "cores": threads, "kind": "port",
             "sample": f"fp32 CPU oracle on configs[0] (B=16, frame_stack 10, 100-step DDPM): 1 of {n_chunks} chunks x {N} steps timed "
                       f"({dt:.1f} s on {threads} threads), whole job = {n_chunks}x",
             "ms_per_denoiser_call": round(dt / N * 1e3, 1),
             "one_thread": {"value": round(B / (dt1 * N * n_chunks), 4), "cores": 1, "ms_per_denoiser_call": round(dt1 * 1e3, 1),
                            "sample": "10 denoiser calls of the same chunk on 1 thread, scaled to 8 chunks x 100 steps"}}
+
+
+def cpu_baseline_dit(B=16, N=100, sample_steps=10):
+    """The GEMM-heavy variant beside it: the decoder twin, DiT hidden 256 / 4 blocks / 8 heads, 100-step DDPM (cosine), B = 16,
+    deterministic sampling (k = 1), fp32 CPU oracle on every allowed thread.  Bounded sample: `sample_steps` of the 100 steps are
+    timed (every step costs the same: one denoiser call + the scheduler update), the whole job is N / sample_steps times that."""
+    from autodiffusion_amd import dit, synth
+    from oracle import nets
+    dec = dit.DiffusionDecoder(dit.dit_config(256, 4, 8, "DiT", diffusion_timesteps=N))
+    synth.fill_module_(dec, 11)
+    sd = {k[len("model.model."):]: v.detach().float() for k, v in dec.state_dict().items() if k.startswith("model.model.")}
+    state = synth.hidden_state(B, 256, 7)
+    x = synth.noise(B, (), (80, 4), 1234)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        nets.dit_forward(sd, x, torch.full((B,), 5, dtype=torch.long), state, 8, "DiT")     # warm-up call
+        t0 = time.perf_counter()
+        for k in range(sample_steps):
+            x = x - 0.01 * nets.dit_forward(sd, x, torch.full((B,), N - 1 - k, dtype=torch.long), state, 8, "DiT")
+        dt = (time.perf_counter() - t0) / sample_steps
+    return {"value": round(B / (dt * N), 4), "unit": "trajectories/s", "cores": threads, "kind": "port", "ms_per_denoiser_call": round(dt * 1e3, 1),
+            "sample": f"fp32 CPU oracle, DiT d=256 L=4 h=8, B={B}, {N}-step DDPM: {sample_steps} denoiser calls timed on {threads} threads, "
+                      f"whole job = {N} calls"}
 
 
 def dit_gemm(dev):

@@ -90,6 +90,11 @@ int adx_op_linear_planes(const void* x_planes, const void* w_blocked, const floa
  * adx_op_linear_staged's bit for bit.  Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU race. */
 int adx_op_linear_noalloc(const float* x, const void* w, const float* bias, float* y, int M, int N, int K, int act, int prec,
                           void* stream);
+/* Per-device set-up of the entry point above (no counterpart in the reference either): call once per device, with that device
+ * current and outside any stream capture -- it resolves the fixed array's address (which loads the code object) and sets kernel
+ * attributes, neither of which may happen while a stream is being captured.  adx_op_linear_noalloc does it by itself on its first
+ * call on a device; callers that record it into a hipGraph call this (or one eager adx_op_linear_noalloc) beforehand. */
+int adx_noalloc_init(void);
 size_t adx_noalloc_scratch_bytes(void);
 int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 

@@ -64,3 +64,34 @@ def test_linear_noalloc_equals_staged(precision):
         _call(lib, "adx_op_linear_noalloc", x, w, None, M, N, K, 0, prec)
     with pytest.raises(_lib.AdxError, match="staged kernel needs"):
         _call(lib, "adx_op_linear_noalloc", x, w, None, 100, 64, 64, 0, prec)
+
+
+def test_linear_noalloc_under_graph_capture():
+    """The callers this entry point exists for: after adx_noalloc_init() (outside any capture) the call is recorded into a graph
+    on a capturing stream and replayed; the replay writes the same bits as an eager call, also after the inputs changed in place."""
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from autodiffusion_amd import _lib, ops
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    _lib.check(lib.adx_noalloc_init(), "adx_noalloc_init")
+    M, N, K = 8192, 1024, 512
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = ops.prepare_weight((torch.randn(N, K, generator=g) / K ** 0.5).to(dev), "bf16x3")
+    b = torch.randn(N, generator=g).to(dev)
+    y = torch.zeros(M, N, device=dev)
+    prec = _lib.PRECISIONS["bf16x3"]
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            _lib.check(lib.adx_op_linear_noalloc(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), M, N, K, _lib.ACT_NONE, prec,
+                                                 _lib.current_stream()), "adx_op_linear_noalloc (capturing)")
+    torch.cuda.current_stream().wait_stream(side)
+    for scale in (1.0, -0.5):
+        x.mul_(scale)
+        y.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, _call(lib, "adx_op_linear_noalloc", x, w, b, M, N, K, _lib.ACT_NONE, prec))
