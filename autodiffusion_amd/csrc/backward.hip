@@ -35,6 +35,19 @@ __global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b
     if (i < n) out[i] = a[i] + b[i];
 }
 
+// four elements per lane and access, for n a multiple of 4 and 16-byte aligned buffers (the scalar forms move 4 bytes per lane
+// and reach 0.64 of the HBM peak); OP 0: a + b, 1: a * b
+template <int OP>
+__global__ __launch_bounds__(256) void binary4_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 u = a[i], v = b[i];
+    out[i] = OP == 0 ? make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w) : make_float4(u.x * v.x, u.y * v.y, u.z * v.z, u.w * v.w);
+}
+inline bool vec4_ok(int64_t n, const void* a, const void* b, const void* c) {
+    return (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 // y = x Phi(x), Phi the standard normal distribution function (torch's default "gelu": the erf form)
 __global__ __launch_bounds__(256) void gelu_kernel(const float* x, float* y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -730,13 +743,21 @@ void chunking(int64_t M, int64_t* rows_per_chunk, int* n_chunks) {
 // ================================================================================================ C ABI
 ADX_API int adx_op_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
     if (!a || !b || !out || n <= 0) return fail(ADX_EINVAL, "add: null pointer or empty shape");
-    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    if (vec4_ok(n, a, b, out))
+        hipLaunchKernelGGL(binary4_kernel<0>, dim3(blocks_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                           reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n >> 2);
+    else
+        hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     return done(hipGetLastError(), "add");
 }
 
 ADX_API int adx_op_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
     if (!a || !b || !out || n <= 0) return fail(ADX_EINVAL, "mul: null pointer or empty shape");
-    hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    if (vec4_ok(n, a, b, out))
+        hipLaunchKernelGGL(binary4_kernel<1>, dim3(blocks_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(a),
+                           reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n >> 2);
+    else
+        hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     return done(hipGetLastError(), "mul");
 }
 

@@ -40,7 +40,7 @@ struct EngineA final : adx_engine {
     float *X0 = nullptr, *XA = nullptr, *XB = nullptr, *H1 = nullptr, *QKV = nullptr, *ATT = nullptr, *FF = nullptr;
     float *Y = nullptr, *YN = nullptr, *DQKV = nullptr, *DATT = nullptr, *DFF = nullptr, *MKV = nullptr, *DQ = nullptr;
     float *XS0 = nullptr, *XS1 = nullptr, *MOUT = nullptr, *TRAN = nullptr, *PRIN = nullptr, *TRAW = nullptr, *PRAW = nullptr,
-          *CHO = nullptr, *TE = nullptr;
+          *CHO = nullptr, *TE = nullptr, *ZBUF = nullptr;
     // elide level 2: layer-0 attention cache.  QKV0: in_proj(LN1(X0)) of every conditioning row, valid for a whole chunk
     // (rows >= 1 do not depend on the diffusion step); ST: softmax state of every query row >= 1 over key rows >= 1;
     // tqkv0: per-step q/k/v of the time token (identical for every batch item), [n_steps][3d].
@@ -166,6 +166,7 @@ struct EngineA final : adx_engine {
         take(&TRAN, (size_t)B * NP * Cp); take(&PRIN, (size_t)B * NP * Cp);
         take(&TRAW, (size_t)B * NP * Cp); take(&PRAW, (size_t)B * NP * Cp); take(&CHO, BT * Cin);
         take(&TE, (size_t)B * d);
+        if (Cout != Cin) take(&ZBUF, BT * Cout);         // latent-carrying sampling: the latent the next chunk is conditioned on
         if (cfg.elide >= 2) { take(&QKV0, BL * 3 * d); take(&ST, BL * H * 6); }
         if (fused) {
             take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
@@ -938,6 +939,94 @@ struct EngineA final : adx_engine {
         if (rc == ADX_OK && staged) ADX_HIP(hipMemcpyAsync(out, g_out, traj_b, hipMemcpyDeviceToDevice, s));
         return rc;
     }
+    // Latent-carrying chunk loop (StrDiffDiT.generate, models/backbone/StrDiffDiT.py:202-235, with DiffusionTransitionModel.
+    // conditional_sample, models/diffusion_loss/diffusion_transition.py:43-78): the denoiser returns a latent z (B, T, Cout);
+    // x_from_z maps it to the Cin-wide model output the scheduler step consumes; every chunk starts from its prior (no initial
+    // draw); the latent of a chunk's last step, through z_emb, is the next chunk's transition; the prior's first frame is zeroed;
+    // out = sample * std + mean.  All chunks x steps in one captured graph.  noise: [n_chunks][n_noise][B][T * Cin].
+    int generate_transition(int B, int S, int fs, const float* maps, const float* prior_full, const float* init_z, const float* noise, int n_noise,
+                            const float* mean_std, float* out, unsigned flags, hipStream_t s) {
+        ADX_TRY(check_ready(B, "generate_transition"));
+        if (steps.empty()) { set_error("generate_transition: no schedule set"); return ADX_ESTATE; }
+        if (Cin != 4 || Cp != 4 || Cout == Cin || !ZBUF) { set_error("generate_transition: needs in_dim = prior_dim = 4 and a latent head (out_dim != in_dim)"); return ADX_EINVAL; }
+        if (fs <= 0 || S % fs) { set_error("Number of frames must be divisible by frame stack size"); return ADX_EINVAL; }
+        if (fs != T || NP != fs) { set_error("generate_transition: frame_stack does not match the engine's token layout"); return ADX_EINVAL; }
+        const Param *ze = find("z_emb.weight"), *zb = find("z_emb.bias"), *xw = find("x_from_z.weight"), *xb = find("x_from_z.bias");
+        if (!ze || !zb || !xw || !xb || ze->shape != std::vector<int64_t>{Cp, Cout} || xw->shape != std::vector<int64_t>{Cin, Cout}) {
+            set_error("generate_transition: z_emb.weight (prior_dim, z_dim) / z_emb.bias / x_from_z.weight (in_dim, z_dim) / x_from_z.bias must be set");
+            return ADX_EINVAL;
+        }
+        const int draws = n_schedule_draws();
+        if (draws > 0 && (!noise || n_noise < draws)) { set_error("generate_transition: the schedule draws more noise tensors than were supplied"); return ADX_EINVAL; }
+        const int n_chunks = S / fs, chunk = fs * 4;
+        const int64_t n = (int64_t)B * chunk;
+        char shape[160], ptrs[200];
+        snprintf(shape, sizeof shape, "t|%d|%d|%d|%d|%u|%d", B, S, fs, n_noise, flags, schedule_version);
+        snprintf(ptrs, sizeof ptrs, "|%p|%p|%p|%p|%p|%p", (const void*)maps, (const void*)prior_full, (const void*)init_z, (const void*)noise,
+                 (const void*)mean_std, (void*)out);
+        const bool staged = use_staging(shape, ptrs, flags);
+        const size_t maps_b = cfg.map_cond ? sizeof(float) * (size_t)B * nmaps * cfg.maps_dim : 0;
+        const size_t traj_b = sizeof(float) * (size_t)B * S * 4, z_b = sizeof(float) * (size_t)T * Cout, ms_b = sizeof(float) * 8;
+        const size_t noise_b = noise ? sizeof(float) * (size_t)n_chunks * n_noise * n : 0;
+        float* g_out = out;
+        if (staged) {
+            StagePlan pl;
+            const size_t o_maps = pl.take(maps_b), o_prior = pl.take(traj_b), o_z = pl.take(z_b), o_noise = pl.take(noise_b), o_ms = pl.take(ms_b),
+                         o_out = pl.take(traj_b);
+            ADX_TRY(ensure_stage(pl.total));
+            auto stage_in = [&](const float*& p, size_t off, size_t bytes) -> hipError_t {
+                if (!bytes || !p) return hipSuccess;
+                hipError_t e = hipMemcpyAsync(stage_buf + off, p, bytes, hipMemcpyDeviceToDevice, s);
+                p = reinterpret_cast<const float*>(stage_buf + off);
+                return e;
+            };
+            ADX_HIP(stage_in(maps, o_maps, maps_b));
+            ADX_HIP(stage_in(prior_full, o_prior, traj_b));
+            ADX_HIP(stage_in(init_z, o_z, z_b));
+            ADX_HIP(stage_in(noise, o_noise, noise_b));
+            ADX_HIP(stage_in(mean_std, o_ms, ms_b));
+            g_out = reinterpret_cast<float*>(stage_buf + o_out);
+        }
+        maps_batch = -1;
+        const bool cached = cfg.elide >= 2 && n_enc >= 2;
+        const std::string key = std::string(shape) + (staged ? "|staged" : ptrs);
+        const int rc = run(key, flags, s, [&](hipStream_t cs) -> int {
+            ADX_TRY(embed_maps(B, maps, cs));
+            if (cached) ADX_TRY(build_map_cache(B, cs));
+            ADX_HIP(copy2d(init_z, (int64_t)T * Cout, 1, ZBUF, (int64_t)T * Cout, B, T * Cout, cs));          // the initial latent, one copy per item
+            for (int c = 0; c < n_chunks; ++c) {
+                ADX_HIP(copy2d(prior_full + (int64_t)c * chunk, (int64_t)S * 4, 0, PRAW, chunk, B, chunk, cs));
+                if (c == 0) ADX_HIP(hipMemset2DAsync(PRAW, sizeof(float) * chunk, 0, sizeof(float) * 4, B, cs));   // first frame of the prior := 0
+                LinearArgs zl = lin(ZBUF, Cout, "z_emb.weight", 0, Cp, Cout, "z_emb.bias", TRAW, Cp, B * T, ACT_NONE, PREC_F32);
+                ADX_HIP(linear(zl, cs));
+                ADX_TRY(embed_prior(B, TRAW, PRAW, cs));
+                if (cached) {
+                    ADX_TRY(set_time(B, temb_table, 0, cs));
+                    ADX_TRY(build_chunk_cache(B, cs));
+                }
+                float* xc = XS0; float* xn = XS1;
+                ADX_HIP(copy2d(PRAW, n, 0, xc, n, 1, (int)n, cs));                                           // the sample starts from the prior
+                const float* nz = noise ? noise + (int64_t)c * n_noise * n : nullptr;
+                for (size_t k = 0; k < steps.size(); ++k) {
+                    if (!fused) ADX_TRY(set_time(B, temb_table + k * d, 0, cs));
+                    const int zi = (int)steps[k].z_index;
+                    const float* z = (zi >= 0 && steps[k].c3 != 0.f) ? nz + (int64_t)zi * n : nullptr;
+                    StepIO io;
+                    io.step = cached ? (int)k : -1;
+                    ADX_TRY(run_net(B, xc, MOUT, cs, io));
+                    ADX_HIP(linear(lin(MOUT, Cout, "x_from_z.weight", 0, Cin, Cout, "x_from_z.bias", CHO, Cin, B * T, ACT_NONE, PREC_F32), cs));
+                    ADX_HIP(sched_step(xc, CHO, z, xn, nullptr, n, steps_dev + k, cs));
+                    float* tmp = xc; xc = xn; xn = tmp;
+                }
+                if (c + 1 < n_chunks) ADX_HIP(copy2d(MOUT, (int64_t)B * T * Cout, 0, ZBUF, (int64_t)B * T * Cout, 1, B * T * Cout, cs));
+                if (mean_std) ADX_HIP(affine_channels(xc, mean_std, mean_std + 4, CHO, n / 4, 4, cs));
+                ADX_HIP(copy2d(mean_std ? CHO : xc, chunk, 0, g_out + (int64_t)c * chunk, (int64_t)S * 4, B, chunk, cs));
+            }
+            return ADX_OK;
+        });
+        if (rc == ADX_OK && staged) ADX_HIP(hipMemcpyAsync(out, g_out, traj_b, hipMemcpyDeviceToDevice, s));
+        return rc;
+    }
 };
 
 }  // namespace
@@ -994,4 +1083,12 @@ ADX_API int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const f
     if (!a) return ADX_EINVAL;
     if (!prior_full || !init_x || !out || (a->cfg.map_cond && !maps)) { set_error("generate_a: null pointer"); return ADX_EINVAL; }
     return a->generate(B, S, frame_stack, maps, prior_full, init_x, noise, n_noise, out, flags, (hipStream_t)stream);
+}
+
+ADX_API int adx_generate_transition(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full, const float* init_z,
+                                    const float* noise, int n_noise, const float* mean_std, float* out, unsigned flags, void* stream) {
+    EngineA* a = as_a(e, "generate_transition");
+    if (!a) return ADX_EINVAL;
+    if (!prior_full || !init_z || !out || (a->cfg.map_cond && !maps)) { set_error("generate_transition: null pointer"); return ADX_EINVAL; }
+    return a->generate_transition(B, S, frame_stack, maps, prior_full, init_z, noise, n_noise, mean_std, out, flags, (hipStream_t)stream);
 }

@@ -76,6 +76,19 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* x0, const fl
     if (v) v[i] = a * n - b * x;
 }
 
+// the same with four elements per lane and access (row_len a multiple of 4, 16-byte aligned buffers)
+__global__ __launch_bounds__(256) void q_sample4_kernel(const float4* __restrict__ x0, const float4* __restrict__ noise, const int64_t* __restrict__ t,
+                                                         const float* __restrict__ sa, const float* __restrict__ s1, float4* __restrict__ xt,
+                                                         float4* __restrict__ v, int64_t total4, int row_len4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int64_t tb = t[i / row_len4];
+    const float a = sa[tb], b = s1[tb];
+    const float4 x = x0[i], n = noise[i];
+    xt[i] = make_float4(a * x.x + b * n.x, a * x.y + b * n.y, a * x.z + b * n.z, a * x.w + b * n.w);
+    if (v) v[i] = make_float4(a * n.x - b * x.x, a * n.y - b * x.y, a * n.z - b * x.z, a * n.w - b * x.w);
+}
+
 // loss_rows[b] = weight[t[b]] * mean_e (out[b][e] - target[b][e])^2: one wavefront per row, lanes stride the row, the
 // lane sums are combined in a fixed butterfly order (the result does not depend on the launch shape).
 __global__ __launch_bounds__(256) void weighted_mse_kernel(const float* out, const float* target, const int64_t* t, const float* weight,
@@ -123,8 +136,14 @@ hipError_t q_sample(const float* x0, const float* noise, const int64_t* t, const
                     float* v, int n_rows, int row_len, hipStream_t stream) {
     const int64_t total = (int64_t)n_rows * row_len;
     if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x0, noise, t, sqrt_acp, sqrt_1m_acp, xt, v,
-                       total, row_len);
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((row_len & 3) == 0 && al(x0) && al(noise) && al(xt) && al(v))
+        hipLaunchKernelGGL(q_sample4_kernel, dim3((unsigned)(((total >> 2) + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const float4*>(x0),
+                           reinterpret_cast<const float4*>(noise), t, sqrt_acp, sqrt_1m_acp, reinterpret_cast<float4*>(xt), reinterpret_cast<float4*>(v),
+                           total >> 2, row_len >> 2);
+    else
+        hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x0, noise, t, sqrt_acp, sqrt_1m_acp, xt, v,
+                           total, row_len);
     return hipGetLastError();
 }
 

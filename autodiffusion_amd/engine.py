@@ -54,6 +54,25 @@ class Engine:
             self.load((n[len(prefix):] if n.startswith(prefix) else n, p) for n, p in params)
             self._stamp = stamp
 
+    def set_extra(self, named: Iterable[Tuple[str, torch.Tensor]]):
+        """Tensors beside the denoiser's own (the latent maps of the transition wrapper), re-sent only when one changed."""
+        named = list(named)
+        stamp = tuple((n, p.data_ptr(), p._version, str(p.device)) for n, p in named)
+        if stamp != getattr(self, "_extra_stamp", None):
+            self.load(named)
+            self._extra_stamp = stamp
+
+    def generate_transition(self, maps, prior_full, init_z, noise, mean_std, frame_stack: int, flags: int = 0,
+                            out: Optional[torch.Tensor] = None):
+        """Latent-carrying chunk loop in one captured graph (``adx_generate_transition``)."""
+        B, S = prior_full.shape[0], prior_full.shape[1]
+        n_noise = 0 if noise is None else noise.shape[1]
+        if out is None:
+            out = torch.empty(B, S, 4, device=prior_full.device, dtype=torch.float32)
+        check(self.lib.adx_generate_transition(self.h, B, S, int(frame_stack), ptr(maps), ptr(prior_full), ptr(init_z), ptr(noise), n_noise,
+                                               ptr(mean_std), ptr(out), flags, current_stream()), "adx_generate_transition")
+        return out
+
     def reserve(self, batch: int):
         check(self.lib.adx_engine_reserve(self.h, int(batch)), "adx_engine_reserve")
 

@@ -12,7 +12,9 @@ The reference imports the denoiser of this variant (``TransformerForDiffusion``,
 recovered.  Here ``z`` takes the transition slot of the encoder/decoder ``Transformer`` (whose embedding of that slot
 is named ``prior_z_emb``) through one extra Linear ``z_emb (z_dim -> prior_dim)``; everything else is the reference's
 ``Transformer`` with ``output_dim = z_dim``.  The scheduler follows the public DDPMScheduler semantics
-(``schedules.diffusers_rows``).  Every product runs in the HIP library; the step loop is host-side.  ``forward()`` of both
+(``schedules.diffusers_rows``).  ``StrDiffDiT.generate`` runs all chunks x steps as ONE captured graph inside the engine
+(``adx_generate_transition``: fused encoder-row pipeline per step, the decoder's operators, x_from_z, the scheduler step, the
+latent carried on the device); ``generate_eager`` / ``DiffusionTransitionModel.generate`` drive the same operators from the host.  ``forward()`` of both
 classes returns the evaluation-time VALUE of the training loss (StrDiffDiT.py:96-155, diffusion_transition.py:95-130) without
 an autograd graph.
 """
@@ -39,7 +41,7 @@ class DiffusionTransitionModel(nn.Module):
         self.diffusion = Transformer(
             input_dim=cfg.x_shape[-1], output_dim=z_dim, horizon=cfg.frame_stack, n_cond_steps=cfg.n_maps_token,
             cond_dim=cfg.cond_dim, n_prior_steps=cfg.frame_stack, prior_dim=cfg.prior_dim, causal_attn=True,
-            precision=getattr(cfg, "precision", "fp32"), elide=min(int(getattr(cfg, "elide", 2)), 2))
+            precision=getattr(cfg, "precision", "fp32"), elide=int(getattr(cfg, "elide", 3)))
         self.z_emb = _Lin(z_dim, cfg.prior_dim)
         self.x_from_z = _Lin(cfg.z_shape[1], cfg.x_shape[0])
         if cfg.scheduler.prediction_type != "epsilon":
@@ -152,6 +154,37 @@ class StrDiffDiT(nn.Module):
             raise ValueError("Number of frames must be divisible by frame stack size")
         if getattr(self.cfg, "context_frames", 0) % self.frame_stack != 0:
             raise ValueError("Number of context frames must be divisible by frame stack size")
+        n_chunks = S // self.frame_stack
+        tm = self.transition_model
+        rows = tm.schedule_rows()
+        draws = schedules.n_noise_draws(rows)
+        fs = self.frame_stack
+        if noise is None and draws > 0:               # the library's counter-based generator: chunk c draws with seed + c
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            noise = torch.stack([ops.randn(draws, B, fs * C, seed + c, row0, device=trajectory_prior.device) for c in range(n_chunks)])
+        eng = tm.diffusion.engine()                   # the denoiser's engine (level-3 elision: fused encoder rows, unfused decoder)
+        eng.set_extra([("z_emb.weight", tm.z_emb.weight), ("z_emb.bias", tm.z_emb.bias), ("x_from_z.weight", tm.x_from_z.weight),
+                       ("x_from_z.bias", tm.x_from_z.bias)])
+        eng.set_schedule(rows)
+        if self.learnable_init_z:
+            init_z = _lib.f32c(self.init_z)
+        else:
+            init_z = torch.zeros(*self.z_shape, device=trajectory_prior.device)
+        stamp = (self.data_mean.data_ptr(), self.data_mean._version, self.data_std.data_ptr(), self.data_std._version, str(trajectory_prior.device))
+        if self.__dict__.get("_ms_stamp") != stamp:   # {mean[4], std[4]} on the device, rebuilt only when a buffer changed
+            self.__dict__["_ms"] = torch.cat([self.data_mean.float().reshape(4), self.data_std.float().reshape(4)]).to(trajectory_prior.device).contiguous()
+            self.__dict__["_ms_stamp"] = stamp
+        out = eng.generate_transition(_lib.f32c(maps_info), _lib.f32c(trajectory_prior), init_z,
+                                      None if noise is None else _lib.f32c(noise).reshape(n_chunks, -1, B, fs * C), self.__dict__["_ms"], fs)
+        return {"traj_logits": out}
+
+    @torch.no_grad()
+    def generate_eager(self, noise: Optional[torch.Tensor] = None, seed: Optional[int] = None, row0: int = 0, **kwargs):
+        """The same loop driven from the host, one library call per operator (``DiffusionTransitionModel.generate`` per chunk):
+        the form the captured loop is checked against."""
+        trajectory_prior, maps_info = kwargs["trajectory_prior"], kwargs["maps_info"]
+        B, S, C = trajectory_prior.shape
         n_chunks = S // self.frame_stack
         conditions = _lib.f32c(trajectory_prior).clone()
         conditions[:, :1] = 0.0                                       # StrDiffDiT.py:182

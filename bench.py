@@ -253,6 +253,41 @@ def bench_dit(args, dev):
     print(json.dumps(line), flush=True)
 
 
+def bench_transition(args, dev):
+    """config/strDiffDiT.yaml as written: the latent-carrying wrapper (StrDiffDiT), frame_stack 10 -> 8 chunks, latent 10 x 768,
+    10 diffusers-style DDPM steps of 100 (squaredcos_cap_v2), B scenarios; all chunks x steps replayed from one captured graph.
+    Parity of this wrapper is unpinned (its denoiser class is missing from the reference tree)."""
+    from autodiffusion_amd import schedules, synth, transition
+    B = args.batch or 1024
+    cfg = transition.transition_config(frame_stack=10, z_dim=768, num_train_timesteps=100, num_inference_steps=10, precision=args.precision)
+    m = transition.StrDiffDiT(cfg)
+    synth.reference_init_(m, 11)
+    m = m.to(dev).eval()
+    maps, prior = synth.maps_info(B, 7).to(dev), (synth.trajectory_prior(B, 7) * 0.01).to(dev)
+    draws = schedules.n_noise_draws(m.transition_model.schedule_rows())
+    noise = synth.noise(B, (8, draws), (10, 4), 1234).to(dev)
+
+    def step():
+        return m.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"]
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    assert bool(torch.isfinite(out).all())
+    print(json.dumps({
+        "metric": "denoised trajectories/sec (8s, 80-pt)", "value": round(B / dt, 2), "unit": "trajectories/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": "strDiffDiT.yaml literal: latent-carrying refiner (enc/dec Transformer d=32 with a 768-wide latent head), frame_stack 10 x 8 "
+                               "chunks, 10 DDPM steps of 100, random init, synthetic nuPlan-shaped conditioning", "batch_per_gpu": B, "global_batch": B,
+                   "denoiser_calls_per_step": 80, "parallelism": "dp1", "precision": args.precision,
+                   "captures": m.transition_model.diffusion.engine().capture_count()}}), flush=True)
+
+
 def cpu_baseline():
     """BASELINE.json configs[0] on the host cores with the fp32 CPU oracle: B = 16, frame_stack 10, 100-step DDPM (cosine,
     pred_noise).  Bounded sample: ONE of the 8 chunks with all 100 steps on every allowed thread (the 8 chunks are
@@ -431,7 +466,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 1024 for the refiner, the configured batch)")
-    ap.add_argument("--workload", default="refiner", choices=["refiner"] + sorted(DIT_WORKLOADS),
+    ap.add_argument("--workload", default="refiner", choices=["refiner", "strdiffdit"] + sorted(DIT_WORKLOADS),
                     help="refiner = the headline configuration; the DiT decoder workloads run on one GPU only")
     ap.add_argument("--frame-stack", type=int, default=0, help="refiner: points per chunk (default 10; 80 = whole trajectory)")
     ap.add_argument("--n-train", type=int, default=0, help="refiner: training timesteps (default 100)")
@@ -471,8 +506,8 @@ def main():
     L_COND = 1 + 788 + 2 * FS
     if args.workload != "refiner":
         if world > 1:
-            raise SystemExit("the DiT workloads are single-GPU measurements")
-        return bench_dit(args, dev)
+            raise SystemExit("the DiT and latent-carrying workloads are single-GPU measurements")
+        return bench_transition(args, dev) if args.workload == "strdiffdit" else bench_dit(args, dev)
 
     from autodiffusion_amd import schedules
     from autodiffusion_amd.distributed import RowGatherer

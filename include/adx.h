@@ -312,6 +312,20 @@ int adx_sample_a(adx_engine* e, int B, const float* maps, const float* transitio
 int adx_generate_a(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
                    const float* init_x, const float* noise, int n_noise, float* out, unsigned flags, void* stream);
 
+/* Latent-carrying chunk loop (StrDiffDiT.generate, models/backbone/StrDiffDiT.py:202-235, around DiffusionTransitionModel.
+ * conditional_sample, models/diffusion_loss/diffusion_transition.py:43-78) on a variant-A engine whose head is out_dim = z_dim wide:
+ * per chunk of frame_stack points the sample starts from the chunk of prior_full[B][S][4] (first frame of the trajectory zeroed),
+ * every step calls the denoiser with transition = z_emb(latent), maps x_from_z(denoiser latent) to the model output and applies
+ * the step's coefficient row (adx_engine_set_schedule; z_index counts from 0: there is no initial draw); the latent of a chunk's
+ * last step conditions the next chunk; out[B][S][4] = sample * std + mean with mean_std = {mean[4], std[4]} on the device
+ * (nullable: no affine map).  init_z[frame_stack][z_dim] is the first chunk's latent for every item.  The tensors
+ * "z_emb.weight" [4][z_dim], "z_emb.bias", "x_from_z.weight" [4][z_dim], "x_from_z.bias" are set with adx_engine_set_tensor
+ * beside the denoiser's.  noise[n_chunks][n_noise][B][frame_stack * 4].  The reference's denoiser class for this wrapper is
+ * missing from its tree: how the latent enters the network (z_emb into the transition slot) is this library's choice. */
+int adx_generate_transition(adx_engine* e, int B, int S, int frame_stack, const float* maps, const float* prior_full,
+                            const float* init_z, const float* noise, int n_noise, const float* mean_std, float* out,
+                            unsigned flags, void* stream);
+
 /* No counterpart in the reference: per-kernel timing of real calls.  While enabled, sampling calls on this engine run
  * without graph capture and bracket their marked launches with events on the caller's stream; stages of variant A:
  * 1 fused encoder rows, 2 last-layer attention, 3 fused tail, 4 per-chunk cache build, 5 per-call map cache build.

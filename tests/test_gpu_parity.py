@@ -382,6 +382,20 @@ def test_latent_carrying_chunk_loop(dev):
     e = rel_err(out, ref)
     print(f"StrDiffDiT: rel err {e:.2e}")
     assert e < GATE
+    # the captured loop inside the engine against the same operators driven from the host (one library call each)
+    eager = m.generate_eager(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), noise=noise.to(dev))["traj_logits"].cpu()
+    e2 = rel_err(out, eager)
+    print(f"StrDiffDiT: captured loop vs host-driven loop {e2:.2e}")
+    assert e2 < 1e-5
+    eng = m.transition_model.diffusion.engine()
+    c0 = eng.capture_count()
+    for _ in range(3):                          # a caller that hands over fresh tensors every call: one more capture at most
+        again = m.generate(trajectory_prior=prior.to(dev).clone(), maps_info=maps.to(dev).clone(), noise=noise.to(dev).clone())["traj_logits"]
+        assert torch.equal(again.cpu(), out)
+    assert eng.capture_count() - c0 <= 1 and eng.capture_count() <= 2
+    a = m.generate(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), seed=5)["traj_logits"]        # device noise: repeatable per seed
+    assert torch.equal(a, m.generate(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), seed=5)["traj_logits"])
+    assert not torch.equal(a, m.generate(trajectory_prior=prior.to(dev), maps_info=maps.to(dev), seed=6)["traj_logits"])
     with pytest.raises(ValueError):
         m.generate(trajectory_prior=prior[:, :75].to(dev), maps_info=maps.to(dev))
     # forward(): the evaluation-time value of the training loss, draws supplied (parity unpinned, against the oracle's restatement)
