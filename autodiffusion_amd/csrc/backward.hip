@@ -280,6 +280,49 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
 // (block, head, item) order an item's lines were fetched from HBM by up to eight L2s (counters: 17 x the algorithmic bytes).
 // Ids congruent modulo 8 share an XCD, so item = 8 * (slot / per_item) + id % 8: the grid is padded to a multiple of 8 items.
 struct AttnBlock { int b, h, x; bool ok; };
+// ------------------------------------------------------------------------------------------------ dropout
+// nn.Dropout(p) of the reference's training mode (transformer.py:52,70-98; torch's TransformerEncoder / DecoderLayer): every
+// element (and, inside the attention, every (query, key) probability) is kept with probability 1 - p and scaled by 1 / (1 - p).
+// The decision is a pure function of (seed, site, position): a 32-bit integer hash (two multiply / xor-shift rounds) compared with
+// a threshold, so the backward pass -- and the key pass of the attention backward, which walks the pairs in another order --
+// regenerates the mask instead of storing it, and results do not depend on the launch shape.  `site` numbers the dropout layers
+// of one forward pass; seed and site are mixed on the host into `base`.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool drop_keep_elem(uint32_t base, int64_t i, uint32_t thr) {
+    return mix32(mix32(base ^ ((uint32_t)i * 0x9E3779B1u)) ^ ((uint32_t)((uint64_t)i >> 32) * 0x85EBCA77u)) < thr;
+}
+// attention: the hash of (item, head, query) is shared by the whole row of keys
+struct DropArgs {
+    const float* mask = nullptr;     // host-supplied multipliers [B][H][Sq][Skv] (0 or 1 / (1 - p)); otherwise the hash below
+    uint32_t base = 0, thr = 0;
+    float scale = 1.0f;
+};
+__device__ __forceinline__ uint32_t drop_row_hash(uint32_t base, int bh, int i) {
+    return mix32(base ^ ((uint32_t)bh * 0x9E3779B1u) ^ ((uint32_t)i * 0x85EBCA77u));
+}
+__device__ __forceinline__ float drop_mult(const DropArgs& d, uint32_t row_hash, int64_t row_off, int j) {
+    if (d.mask) return d.mask[row_off + j];
+    return mix32(row_hash ^ ((uint32_t)j * 0xC2B2AE3Du)) < d.thr ? d.scale : 0.f;
+}
+
+// y = keep ? x * scale : 0 (x == nullptr: the multipliers themselves, i.e. the mask a caller can inspect or replay)
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint32_t base, uint32_t thr, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float m = drop_keep_elem(base, i, thr) ? scale : 0.f;
+    y[i] = x ? x[i] * m : m;
+}
+// the attention multipliers as a tensor [B][H][Sq][Skv]
+__global__ __launch_bounds__(256) void attention_dropout_mask_kernel(float* __restrict__ out, int BH, int Sq, int Skv, DropArgs d) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)BH * Sq * Skv) return;
+    const int j = (int)(i % Skv), q = (int)((i / Skv) % Sq), bh = (int)(i / ((int64_t)Skv * Sq));
+    out[i] = drop_mult(d, drop_row_hash(d.base, bh, q), 0, j);
+}
+
 __device__ __forceinline__ AttnBlock attn_block(int B, int H, int nx) {
     const int per_item = H * nx, id = blockIdx.x, slot = id >> 3, w = slot % per_item;
     AttnBlock r;
@@ -304,9 +347,10 @@ unsigned attn_grid(int B, int H, int nx) { return (unsigned)(((B + 7) / 8) * 8 *
 // at the end:  dq = scale / l * sum_j 2^(s_j - m) (dout . v_j - D) k_j,  log-sum-exp = m + log2 l.
 // HAVE_LSE: stats already holds the log-sum-exp of every query (written by attn_fwd_stats_kernel): the maximum pass is skipped
 // and the weights are the probabilities themselves.
-template <int DH, int PT, bool MASKED, bool HAVE_LSE>
+template <int DH, int PT, bool MASKED, bool HAVE_LSE, bool DROP = false>
 __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, const float* k, const float* v, const float* o, const float* dout,
-                                                              int B, int nx, int H, int Sq, int Skv, float scale, int mask_off, float* dq, float* stats) {
+                                                              int B, int nx, int H, int Sq, int Skv, float scale, int mask_off, float* dq, float* stats,
+                                                              DropArgs dr = DropArgs()) {
     __shared__ float ks[128][DH], vs[128][DH];
     const AttnBlock blk = attn_block(B, H, nx);
     if (!blk.ok) return;
@@ -316,6 +360,8 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
     bool valid[PT];
     int64_t qoff[PT];
     float qs[PT][DH], go[PT][DH], dqa[PT][DH], D[PT], m[PT], l[PT];
+    uint32_t rh[PT];
+    int64_t roff[PT];
     int last_all = 0;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
@@ -323,6 +369,8 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
         valid[u] = iq[u] < Sq;
         const int ic = valid[u] ? iq[u] : Sq - 1;
         qoff[u] = ((int64_t)b * Sq + ic) * ld + h * DH;
+        rh[u] = DROP ? drop_row_hash(dr.base, b * H + h, ic) : 0u;
+        roff[u] = (((int64_t)b * H + h) * Sq + ic) * Skv;
         D[u] = 0.f; m[u] = -INFINITY; l[u] = 0.f;
 #pragma unroll
         for (int e = 0; e < DH; ++e) {
@@ -380,6 +428,7 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
                 float p = exp2_raw(s - m[u]);
                 if (MASKED && j0 + jj > last[u]) p = 0.f;
                 if (!HAVE_LSE) l[u] += p;
+                if constexpr (DROP) dp *= drop_mult(dr, rh[u], roff[u], min(j0 + jj, Skv - 1));      // d P = d P_hat * multiplier
                 const float ds = p * (dp - D[u]);
 #pragma unroll
                 for (int e = 0; e < DH; ++e) dqa[u][e] = fmaf(ds, kr[e], dqa[u][e]);
@@ -400,9 +449,9 @@ __global__ __launch_bounds__(128) void attn_bwd_query_kernel(const float* q, con
 
 // Forward attention of the training path: o, and per (query, head) the log-sum-exp of the scores (base 2) in stats[..][0], so
 // that the backward needs no pass of its own to find it.  Thread = PT queries, online softmax over blocks of 8 keys.
-template <int DH, int PT, bool MASKED>
+template <int DH, int PT, bool MASKED, bool DROP = false>
 __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, const float* k, const float* v, int B, int nx, int H, int Sq, int Skv,
-                                                              float scale, int mask_off, float* o, float* stats) {
+                                                              float scale, int mask_off, float* o, float* stats, DropArgs dr = DropArgs()) {
     __shared__ float ks[128][DH], vs[128][DH];
     const AttnBlock blk = attn_block(B, H, nx);
     if (!blk.ok) return;
@@ -412,6 +461,8 @@ __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, con
     bool valid[PT];
     int64_t qoff[PT];
     float qs[PT][DH], acc[PT][DH], m[PT], l[PT];
+    uint32_t rh[PT];
+    int64_t roff[PT];
     int last_all = 0;
 #pragma unroll
     for (int u = 0; u < PT; ++u) {
@@ -419,6 +470,8 @@ __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, con
         valid[u] = iq[u] < Sq;
         const int ic = valid[u] ? iq[u] : Sq - 1;
         qoff[u] = ((int64_t)b * Sq + ic) * ld + h * DH;
+        rh[u] = DROP ? drop_row_hash(dr.base, b * H + h, ic) : 0u;
+        roff[u] = (((int64_t)b * H + h) * Sq + ic) * Skv;
         m[u] = -INFINITY; l[u] = 0.f;
 #pragma unroll
         for (int e = 0; e < DH; ++e) { qs[u][e] = q[qoff[u] + e] * (scale * kLog2e); acc[u][e] = 0.f; }
@@ -474,8 +527,9 @@ __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, con
                 for (int e = 0; e < DH; ++e) vr[e] = vs[jj][e];
 #pragma unroll
                 for (int u = 0; u < PT; ++u) {
-                    const float p = exp2_raw(sc[u][w] - mx[u]);
-                    l[u] += p;
+                    float p = exp2_raw(sc[u][w] - mx[u]);
+                    l[u] += p;                              // the softmax is normalised over ALL visible keys; dropout acts on the weights
+                    if constexpr (DROP) p *= drop_mult(dr, rh[u], roff[u], min(j0 + jb + w, Skv - 1));
 #pragma unroll
                     for (int e = 0; e < DH; ++e) acc[u][e] = fmaf(p, vr[e], acc[u][e]);
                 }
@@ -496,10 +550,12 @@ __global__ __launch_bounds__(128) void attn_fwd_stats_kernel(const float* q, con
 }
 
 // Pass over keys: thread = PT keys;  dv_j = sum_i P_ij dout_i,   dk_j = scale * sum_i dS_ij q_i.
-template <int DH, int PT, bool MASKED>
+template <int DH, int PT, bool MASKED, bool DROP = false>
 __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const float* k, const float* v, const float* dout, const float* stats,
-                                                            int B, int nx, int H, int Sq, int Skv, float scale, int mask_off, float* dk, float* dv) {
+                                                            int B, int nx, int H, int Sq, int Skv, float scale, int mask_off, float* dk, float* dv,
+                                                            DropArgs dr = DropArgs()) {
     __shared__ float qsh[128][DH], gsh[128][DH], ssh[128][2];
+    __shared__ uint32_t hsh[DROP ? 128 : 1];                   // row hashes of the staged queries
     const AttnBlock blk = attn_block(B, H, nx);
     if (!blk.ok) return;
     const int b = blk.b, h = blk.h, bx = blk.x;
@@ -535,6 +591,7 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
             const int ii = idx >> 1;
             ssh[ii][idx & 1] = i0 + ii < Sq ? sb[(int64_t)(i0 + ii) * 2 + (idx & 1)] : 0.f;
         }
+        if constexpr (DROP) hsh[threadIdx.x] = drop_row_hash(dr.base, b * H + h, min(i0 + (int)threadIdx.x, Sq - 1));
         __syncthreads();
         const int in = min(128, Sq - i0);
         for (int ii = max(0, first_all - i0); ii < in; ++ii) {
@@ -549,9 +606,14 @@ __global__ __launch_bounds__(128) void attn_bwd_key_kernel(const float* q, const
                 for (int e = 0; e < DH; ++e) { s = fmaf(qr[e], kk[u][e], s); dp = fmaf(gr[e], vv[u][e], dp); }
                 float p = exp2_raw(s - lse);
                 if (MASKED && i0 + ii < first[u]) p = 0.f;
+                float pv = p;                                     // weight of dout_i in dv_j: the dropped-out probability
+                if constexpr (DROP) {
+                    const float mk = drop_mult(dr, hsh[ii], (((int64_t)b * H + h) * Sq + i0 + ii) * Skv, valid[u] ? jk[u] : Skv - 1);
+                    pv *= mk; dp *= mk;
+                }
                 const float ds = p * (dp - Di);
 #pragma unroll
-                for (int e = 0; e < DH; ++e) { dva[u][e] = fmaf(p, gr[e], dva[u][e]); dka[u][e] = fmaf(ds, qr[e], dka[u][e]); }
+                for (int e = 0; e < DH; ++e) { dva[u][e] = fmaf(pv, gr[e], dva[u][e]); dka[u][e] = fmaf(ds, qr[e], dka[u][e]); }
             }
         }
     }
@@ -862,12 +924,30 @@ ADX_API int adx_op_layernorm_bwd(const float* x, const float* gamma, const float
     return done(hipGetLastError(), "layernorm_bwd");
 }
 
-ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H, int Sq, int Skv,
-                                 int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, int stats_have_lse, void* stream) {
+// seed and site mixed into the 32-bit base of the mask hash (splitmix64 finaliser), the keep threshold and the scale of a rate p
+static uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static bool drop_args(float p, uint64_t seed, int site, const float* host_mask, DropArgs* d, const char* who) {
+    if (!(p >= 0.f) || p >= 1.f) { set_error(std::string(who) + ": dropout rate must lie in [0, 1)"); return false; }
+    d->mask = host_mask;
+    d->base = (uint32_t)splitmix64(seed ^ splitmix64((uint64_t)(uint32_t)site + 0x5851F42D4C957F2Dull));
+    const double keep = 1.0 - (double)p;
+    d->thr = keep >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(keep * 4294967296.0);
+    d->scale = (float)(1.0 / keep);
+    return true;
+}
+
+static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H, int Sq, int Skv,
+                              int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, int stats_have_lse, const DropArgs* drp,
+                              void* stream) {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !stats) return fail(ADX_EINVAL, "attention_bwd: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_bwd: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_bwd: batch or head count above 65535");
     hipStream_t s = (hipStream_t)stream;
+    const DropArgs dr = drp ? *drp : DropArgs();
+    if (drp && wide_lds_bytes(Sq, Skv, dh, true)) return fail(ADX_EINVAL, "attention_bwd: attention dropout is built for head widths 4, 8, 16 and 32");
     if (const size_t lds = wide_lds_bytes(Sq, Skv, dh, true)) {
         hipLaunchKernelGGL(attn_wide_bwd_kernel, dim3(H, B), dim3(kWideThreads), lds, s, q, k, v, o, dout, stats, stats_have_lse, H, Sq, Skv, dh, scale,
                            mask_off, dq, dk, dv);
@@ -878,8 +958,13 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
     const dim3 gq(attn_grid(B, H, nq)), gk(attn_grid(B, H, nk));
 #define PT (DH_ <= 16 ? 2 : 1)
 #define ADX_ATTN_BWD3(DH, MASKED, LSE)                                                                                                                  \
-    hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE>), gq, dim3(128), 0, s, q, k, v, o, dout, B, nq, H, Sq, Skv, scale, mask_off, dq, stats);  \
-    hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED>), gk, dim3(128), 0, s, q, k, v, dout, stats, B, nk, H, Sq, Skv, scale, mask_off, dk, dv);
+    if (drp) {                                                                                                                                           \
+        hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE, true>), gq, dim3(128), 0, s, q, k, v, o, dout, B, nq, H, Sq, Skv, scale, mask_off, dq, stats, dr);  \
+        hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED, true>), gk, dim3(128), 0, s, q, k, v, dout, stats, B, nk, H, Sq, Skv, scale, mask_off, dk, dv, dr);        \
+    } else {                                                                                                                                             \
+        hipLaunchKernelGGL((attn_bwd_query_kernel<DH, PT, MASKED, LSE, false>), gq, dim3(128), 0, s, q, k, v, o, dout, B, nq, H, Sq, Skv, scale, mask_off, dq, stats, dr); \
+        hipLaunchKernelGGL((attn_bwd_key_kernel<DH, PT, MASKED, false>), gk, dim3(128), 0, s, q, k, v, dout, stats, B, nk, H, Sq, Skv, scale, mask_off, dk, dv, dr);       \
+    }
 #define ADX_ATTN_BWD2(DH, MASKED) if (stats_have_lse) { ADX_ATTN_BWD3(DH, MASKED, true) } else { ADX_ATTN_BWD3(DH, MASKED, false) }
 #define ADX_ATTN_BWD(DH)                                              \
     case DH: {                                                        \
@@ -900,12 +985,27 @@ ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v,
     return done(hipGetLastError(), "attention_bwd");
 }
 
-ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq, int Skv, int dh,
-                                   float scale, int mask_off, void* stream) {
+ADX_API int adx_op_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H, int Sq, int Skv,
+                                 int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, int stats_have_lse, void* stream) {
+    return attention_bwd_impl(q, k, v, o, dout, B, H, Sq, Skv, dh, scale, mask_off, dq, dk, dv, stats, stats_have_lse, nullptr, stream);
+}
+
+ADX_API int adx_op_attention_bwd_dropout(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H, int Sq,
+                                         int Skv, int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats, int stats_have_lse,
+                                         float p, uint64_t seed, int site, const float* host_mask, void* stream) {
+    DropArgs d;
+    if (!drop_args(p, seed, site, host_mask, &d, "attention_bwd_dropout")) return ADX_EINVAL;
+    return attention_bwd_impl(q, k, v, o, dout, B, H, Sq, Skv, dh, scale, mask_off, dq, dk, dv, stats, stats_have_lse, &d, stream);
+}
+
+static int attention_stats_impl(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq, int Skv, int dh,
+                                float scale, int mask_off, const DropArgs* drp, void* stream) {
     if (!q || !k || !v || !o || !stats) return fail(ADX_EINVAL, "attention_stats: null pointer");
     if (B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_stats: empty shape");
     if (B > 65535 || H > 65535) return fail(ADX_EINVAL, "attention_stats: batch or head count above 65535");
     hipStream_t s = (hipStream_t)stream;
+    const DropArgs dr = drp ? *drp : DropArgs();
+    if (drp && wide_lds_bytes(Sq, Skv, dh, false)) return fail(ADX_EINVAL, "attention_stats: attention dropout is built for head widths 4, 8, 16 and 32");
     if (const size_t lds = wide_lds_bytes(Sq, Skv, dh, false)) {
         hipLaunchKernelGGL(attn_wide_fwd_kernel, dim3(H, B), dim3(kWideThreads), lds, s, q, k, v, H, Sq, Skv, dh, scale, mask_off, o, stats);
         return done(hipGetLastError(), "attention_stats");
@@ -916,8 +1016,11 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
 #define ADX_ATTN_FWD(DH)                                                                                                                         \
     case DH: {                                                                                                                                   \
         constexpr int PT = DH <= 16 ? 2 : 1;                                                                                                     \
-        if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats); \
-        else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats);     \
+        if (drp) {                                                                                                                               \
+            if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false, true>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats, dr); \
+            else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true, true>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats, dr);     \
+        } else if (mask_off < 0) hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, false, false>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats, dr); \
+        else hipLaunchKernelGGL((attn_fwd_stats_kernel<DH, PT, true, false>), gq, dim3(128), 0, s, q, k, v, B, nq, H, Sq, Skv, scale, mask_off, o, stats, dr);     \
         break; }
     switch (dh) {
         ADX_ATTN_FWD(4)
@@ -928,4 +1031,33 @@ ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* 
     }
 #undef ADX_ATTN_FWD
     return done(hipGetLastError(), "attention_stats");
+}
+
+ADX_API int adx_op_attention_stats(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq, int Skv, int dh,
+                                   float scale, int mask_off, void* stream) {
+    return attention_stats_impl(q, k, v, o, stats, B, H, Sq, Skv, dh, scale, mask_off, nullptr, stream);
+}
+
+ADX_API int adx_op_attention_stats_dropout(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq, int Skv,
+                                           int dh, float scale, int mask_off, float p, uint64_t seed, int site, const float* host_mask, void* stream) {
+    DropArgs d;
+    if (!drop_args(p, seed, site, host_mask, &d, "attention_stats_dropout")) return ADX_EINVAL;
+    return attention_stats_impl(q, k, v, o, stats, B, H, Sq, Skv, dh, scale, mask_off, &d, stream);
+}
+
+ADX_API int adx_op_attention_dropout_mask(float* out, int B, int H, int Sq, int Skv, float p, uint64_t seed, int site, void* stream) {
+    if (!out || B <= 0 || H <= 0 || Sq <= 0 || Skv <= 0) return fail(ADX_EINVAL, "attention_dropout_mask: null pointer or empty shape");
+    DropArgs d;
+    if (!drop_args(p, seed, site, nullptr, &d, "attention_dropout_mask")) return ADX_EINVAL;
+    const int64_t n = (int64_t)B * H * Sq * Skv;
+    hipLaunchKernelGGL(attention_dropout_mask_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, out, B * H, Sq, Skv, d);
+    return done(hipGetLastError(), "attention_dropout_mask");
+}
+
+ADX_API int adx_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, int site, void* stream) {
+    if (!y || n <= 0) return fail(ADX_EINVAL, "dropout: null pointer or empty shape");
+    DropArgs d;
+    if (!drop_args(p, seed, site, nullptr, &d, "dropout")) return ADX_EINVAL;
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, d.base, d.thr, d.scale);
+    return done(hipGetLastError(), "dropout");
 }

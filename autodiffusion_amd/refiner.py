@@ -25,10 +25,13 @@ Deviations, all deliberate:
   reproducible and shard-invariant; without it, noise is drawn on the device inside
   the captured graph (counter-based generator keyed by ``seed`` and the global batch
   row ``row0 + b``; ``seed=None`` takes a fresh seed from torch's CPU generator).
-* the loss -- evaluated or trained -- has no dropout (the reference leaves its refiner in
-  train mode inside ``forward``, DiffusionAugmentation.py:109, so its loss is a dropout
-  sample with p = 0.1; here it is the dropout-free value, i.e. the reference with its
-  denoiser in ``.eval()``); the training path warns once about it.  ``forward`` takes
+* dropout: the differentiable training path applies the reference's dropout layers when the
+  denoiser is in training mode (``p_drop_emb`` / ``p_drop_attn``, see ``train.py``), with
+  draws from a device-side integer hash instead of torch's generator, so a training run
+  matches the reference in distribution, and exactly when the multipliers are supplied
+  (``train.set_dropout``).  The value-only loss under ``torch.no_grad()`` runs in the sampling
+  engine and is the dropout-free value whatever the mode (the evaluation entry calls it in
+  ``.eval()``, where the two agree).  ``forward`` takes
   optional ``t`` / ``noise``.
 """
 from __future__ import annotations

@@ -168,6 +168,12 @@ def occupancy_raster(batch: int, channels: int, seed: int = 7, size: int = 224, 
     return torch.from_numpy((g.random((batch, size, size, channels)) < density).astype(np.float32))
 
 
+def dropout_multipliers(shape: Tuple[int, ...], p: float, seed: int, site: int) -> torch.Tensor:
+    """The multipliers of dropout layer number ``site`` of one forward pass: 0 with probability p, else 1 / (1 - p)."""
+    keep = _rng(seed, f"dropout.{site}").random(tuple(shape), dtype=np.float32) >= np.float32(p)
+    return torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - p))
+
+
 def noise(batch: int, lead: Tuple[int, ...], tail: Tuple[int, ...], seed: int = 1234, row0: int = 0) -> torch.Tensor:
     """Gaussian noise ``lead + (B,) + tail`` where batch row r depends only on its global index.
 

@@ -392,7 +392,8 @@ def train_step(dev, B=64, steps=5):
     """One optimisation step of the refiner on the HIP training path at the reference's training batch (script/trainingRefiner.sh:
     per_device_train_batch_size 64): DiffusionAugmentation.forward in gradient mode (the 8 chunks as one batch: q_sample, the
     denoiser with kept activations, min-SNR weighted loss), loss.backward() through the library's backward kernels, SGD update.
-    fp32.  Reported beside the sampling metric; it is not part of ``value``."""
+    fp32, dropout active as in the reference's training (p = 0.1 on embeddings, attention probabilities and the layers' outputs).
+    Reported beside the sampling metric; it is not part of ``value``."""
     from autodiffusion_amd import refiner, synth
     cfg = refiner.refiner_config(frame_stack=FS, diffusion_timesteps=N_TRAIN, objective="pred_noise", beta_schedule="cosine")
     da = refiner.DiffusionAugmentation(cfg)

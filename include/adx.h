@@ -288,6 +288,26 @@ int adx_op_attention_bwd(const float* q, const float* k, const float* v, const f
  * stats[((b*H + h)*Sq + i)*2], the log-sum-exp of query i's scores. */
 int adx_op_attention_stats(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq,
                            int Skv, int dh, float scale, int mask_off, void* stream);
+
+/* Dropout of the training mode.  The reference trains with nn.Dropout(p_drop_emb) on the embedded sequences (transformer.py:52,
+ * 248, 258) and with torch's TransformerEncoderLayer / TransformerDecoderLayer dropout (p_drop_attn there; torch's default 0.1
+ * inside every DiTBlock, libs/diffusionTransformer.py:28) on attention probabilities, attention outputs, the FFN hidden layer and
+ * the FFN output.  Every decision is a pure function of (seed, site, position) -- an integer hash, see csrc/backward.hip -- so
+ * the backward pass regenerates its masks: adx_op_dropout applied to dy with the forward's (seed, site) IS the backward of
+ * adx_op_dropout.  y = x * m, m = 1 / (1 - p) with probability 1 - p, else 0; x == NULL writes m itself (the mask, for
+ * inspection or replay).  `site` numbers the dropout layers of one forward pass. */
+int adx_op_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, int site, void* stream);
+/* adx_op_attention_stats / adx_op_attention_bwd with dropout on the attention probabilities (after the softmax, before the
+ * product with V, as torch's scaled_dot_product_attention applies dropout_p); head widths 4, 8, 16, 32.  host_mask (nullable):
+ * multipliers [B][H][Sq][Skv] (0 or 1 / (1 - p)) that replace the hash -- how a test replays the masks a reference run drew;
+ * adx_op_attention_dropout_mask writes the multipliers the hash gives. */
+int adx_op_attention_stats_dropout(const float* q, const float* k, const float* v, float* o, float* stats, int B, int H, int Sq,
+                                   int Skv, int dh, float scale, int mask_off, float p, uint64_t seed, int site,
+                                   const float* host_mask, void* stream);
+int adx_op_attention_bwd_dropout(const float* q, const float* k, const float* v, const float* o, const float* dout, int B, int H,
+                                 int Sq, int Skv, int dh, float scale, int mask_off, float* dq, float* dk, float* dv, float* stats,
+                                 int stats_have_lse, float p, uint64_t seed, int site, const float* host_mask, void* stream);
+int adx_op_attention_dropout_mask(float* out, int B, int H, int Sq, int Skv, float p, uint64_t seed, int site, void* stream);
 /* Gradient of adx_op_weighted_mse's loss_mean with respect to `out`, times upstream[0] (device scalar; NULL = 1):
  * dout[b][e] = upstream * 2 weight[t[b]] (out - target) / (n_rows * row_len)   (TrajRefiner.py:448-452 under autograd). */
 int adx_op_weighted_mse_bwd(const float* out, const float* target, const int64_t* t, const float* weight,

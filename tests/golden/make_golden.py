@@ -588,6 +588,95 @@ def g16_mmdit_grads():
     g15_twin_grads("MM-DiT", "g16_mmdit_grads")
 
 
+# ----------------------------------------------------------------------------- G19: the same gradients with dropout active
+DSEED = 4242    # dropout multipliers
+
+
+@contextlib.contextmanager
+def dropout_queue(seed):
+    """Replace the two places torch's transformer layers draw dropout from -- torch.nn.functional.dropout (every nn.Dropout) and the
+    probabilities inside torch.nn.functional.scaled_dot_product_attention (what MultiheadAttention calls with need_weights=False) --
+    by the seeded multipliers synth.dropout_multipliers(shape, p, seed, k) for the k-th draw of the forward pass.  The attention is
+    then computed as softmax(q k^T scale + mask) * multipliers @ v, which is what the fused routine computes."""
+    import torch.nn.functional as F
+    real_dropout, real_sdpa = F.dropout, F.scaled_dot_product_attention
+    count = [0]
+
+    def multipliers(shape, p):
+        m = synth.dropout_multipliers(tuple(shape), p, seed, count[0])
+        count[0] += 1
+        return m
+
+    def dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        return x * multipliers(x.shape, p)
+
+    def sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+        assert q.dim() == 4
+        s = q @ k.transpose(-1, -2) * (q.shape[-1] ** -0.5 if scale is None else scale)
+        if is_causal:                   # torch drops the mask it recognised as causal and passes the flag instead
+            assert attn_mask is None
+            attn_mask = torch.ones(q.shape[-2], k.shape[-2], dtype=torch.bool).tril()
+        if attn_mask is not None:
+            s = s.masked_fill(~attn_mask, float("-inf")) if attn_mask.dtype == torch.bool else s + attn_mask
+        pr = torch.softmax(s, dim=-1)
+        if dropout_p > 0.0:
+            pr = pr * multipliers(pr.shape, dropout_p)
+        return pr @ v
+
+    F.dropout, F.scaled_dot_product_attention = dropout, sdpa
+    try:
+        yield count
+    finally:
+        F.dropout, F.scaled_dot_product_attention = real_dropout, real_sdpa
+
+
+def g19_dropout_grads():
+    """G14 and G15 again with every module in training mode (dropout active: p_drop_emb = p_drop_attn = 0.1 in the refiner's
+    denoiser, transformer.py:25-26,52,74,94; torch's default 0.1 inside the DiT blocks' encoder layers,
+    libs/diffusionTransformer.py:31), the multipliers supplied by dropout_queue.  Stored: losses, the number of dropout draws, the
+    gradients (large ones as norm + strided sample)."""
+    out = {}
+    B, fs, N = 2, 10, 100
+    maps = synth.maps_info(B, ISEED)
+    prior = synth.trajectory_prior(B, ISEED)
+    label = prior + synth.noise(B, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
+    refiner = _refiner(fs, N, "pred_noise", "cosine", False, init="seeded")
+    refiner.train()
+    init_x = synth.seeded_param("init_x", (fs, 4), WSEED)
+    t = torch.tensor([37, 81], dtype=torch.long)
+    nz = synth.noise(B, (), (fs, 4), NSEED + 3)
+    with noise_queue([nz]) as q, fixed_randint([t]) as qt, dropout_queue(DSEED) as count:
+        loss, _ = refiner(label[:, :fs].clone(), init_x[None].expand(B, fs, 4).clone(), prior[:, :fs].clone(), maps)
+        assert not q and not qt
+        loss.backward()
+    out["refiner_t"], out["refiner_loss"], out["refiner_draws"] = t, loss.detach(), np.int64(count[0])
+    for name, p in refiner.diffusion.model.named_parameters():
+        if p.grad is not None:
+            grad_record(out, "refiner." + name, p.grad)
+    print("g19 refiner: loss", float(loss), "dropout draws", count[0])
+
+    dec = ref_dd.DiffusionDecoder(dit_config(64, 2, 4, "DiT", n=10))
+    synth.fill_module_(dec, WSEED)
+    dec = dec.float()
+    dec.train()
+    state = synth.hidden_state(B, 64, ISEED).requires_grad_(True)
+    t = torch.tensor([3, 8], dtype=torch.long)
+    nz = synth.noise(B, (), (80, 4), NSEED + 2)
+    with noise_queue([nz]) as q, fixed_randint([t]) as qt, dropout_queue(DSEED + 1) as count:
+        loss, _ = dec(label, state)
+        assert not q and not qt
+        loss.backward()
+    out["twin_t"], out["twin_loss"], out["twin_draws"] = t, loss.detach(), np.int64(count[0])
+    for pname, p in dec.model.model.named_parameters():
+        if p.grad is not None:
+            grad_record(out, "twin." + pname, p.grad)
+    out["twin_grad_state"] = state.grad
+    print("g19 twin: loss", float(loss), "dropout draws", count[0])
+    save("g19_dropout_grads", **out)
+
+
 # ----------------------------------------------------------------------------- G17: C5 at its own depth and loop length
 def g17_c5_loop():
     """BASELINE configs[4] as configured: DiT hidden 1024, 24 blocks, 16 heads, 200-step ancestral DDPM (cosine), stochastic, B = 2,
@@ -676,7 +765,7 @@ def g18_raster_encoder():
     save("g18_raster_encoder", **out)
 
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
-       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop, "g18": g18_raster_encoder}
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop, "g18": g18_raster_encoder, "g19": g19_dropout_grads}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

@@ -1194,6 +1194,7 @@ def test_twin_forward_loss(dev, golden, backbone):
     dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, backbone, diffusion_timesteps=10))
     synth.fill_module_(dec, WSEED)
     dec = dec.to(dev).train()
+    dec.model.model.eval()                          # dropout off, as the fixture was recorded
     loss, logits = dec(T(g["label"]).to(dev), synth.hidden_state(2, 64, ISEED).to(dev), t=T(g["twin_t"]).to(dev),
                        noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
     np.testing.assert_allclose(float(loss), float(g[f"twin_{backbone}_loss"]), rtol=1e-3)

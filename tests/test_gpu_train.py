@@ -137,7 +137,9 @@ def _refiner(dev, fs=10, N=100, obj="pred_noise", sched="cosine"):
     from autodiffusion_amd import refiner, synth
     tr = refiner.TrajectoryRefiner(refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N, objective=obj, beta_schedule=sched))
     synth.fill_module_(tr, WSEED)
-    return tr.to(dev).train()
+    tr = tr.to(dev).train()
+    tr.diffusion.model.eval()           # the wrapper in training mode (it returns the loss), the denoiser without dropout: as G14 was recorded
+    return tr
 
 
 def _g14_inputs(dev, fs=10):
@@ -187,6 +189,7 @@ def test_init_x_gradient_and_a_training_step(dev):
     with torch.no_grad():
         da.init_x.copy_(synth.seeded_param("init_x", (fs, 4), WSEED))
     da = da.to(dev).train()
+    da.diffusion.diffusion.model.eval()             # no dropout: the comparison below is with a dropout-free computation
     maps, prior = synth.maps_info(2, ISEED), synth.trajectory_prior(2, ISEED)
     label = prior + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
     t = torch.from_numpy(np.random.default_rng(5).integers(0, N, size=(8, 2)).astype(np.int64))
@@ -234,7 +237,9 @@ def test_distributed_data_parallel_wraps_the_training_path(dev):
     def build():
         da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=fs, diffusion_timesteps=N))
         synth.fill_module_(da.diffusion, WSEED)
-        return da.to(dev).train()
+        da = da.to(dev).train()
+        da.diffusion.diffusion.model.eval()         # no dropout: the two modules must see the same computation
+        return da
     plain = build()
     plain(trajectory_prior=prior, maps_info=maps, trajectory_label=label, t=t, noise=noise).loss.backward()
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -264,6 +269,7 @@ def test_explicit_wrapper_gradients(dev):
     with torch.no_grad():
         m.init_x.copy_(synth.seeded_param("init_x", (fs * 4,), WSEED))
     m = m.to(dev).train()
+    m.diffusion.diffusion.eval()                    # no dropout: compared with reverse-mode differentiation of the dropout-free oracle
     n_chunks, W = 80 // fs, fs * 4
     maps, prior = synth.maps_info(B, ISEED), synth.trajectory_prior(B, ISEED)
     label = prior + synth.noise(B, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])
@@ -343,6 +349,7 @@ def test_decoder_twin_gradients_match_the_reference(dev, golden, backbone, fixtu
     dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, backbone, diffusion_timesteps=10))
     synth.fill_module_(dec, WSEED)
     dec = dec.to(dev).train()
+    dec.model.model.eval()                          # the network without dropout, as the fixtures were recorded
     state = synth.hidden_state(2, 64, ISEED).to(dev).requires_grad_(True)
     label = (synth.trajectory_prior(2, ISEED) + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])).to(dev)
     loss, logits = dec(label, state, t=T(g["t"]).to(dev), noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
@@ -363,3 +370,176 @@ def test_decoder_twin_gradients_match_the_reference(dev, golden, backbone, fixtu
         val, _ = dec(label, state, t=T(g["t"]).to(dev), noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
     assert not val.requires_grad
     np.testing.assert_allclose(float(val), float(g["loss"]), rtol=1e-3)
+
+
+# ------------------------------------------------------------------ dropout
+DSEED = 4242
+
+
+def _seeded_multipliers(dev, seed):
+    from autodiffusion_amd import synth
+    return lambda k, p, shape: synth.dropout_multipliers(shape, p, seed, k).to(dev)
+
+
+def _hash_multipliers(dev, seed, log=None):
+    """The multipliers the device hash gives, materialised layer by layer (attention layers are the 4-D ones)."""
+    from autodiffusion_amd import train
+
+    def make(k, p, shape):
+        site = train.DropSite(p, seed, k, None)
+        m = train.attention_dropout_mask(*shape, site, dev) if len(shape) == 4 else train.dropout_mask(shape, site, dev)
+        if log is not None:
+            log.append(m)
+        return m
+    return make
+
+
+def test_dropout_operator(dev):
+    """adx_op_dropout: multipliers are 0 or 1 / (1 - p), the keep rate is 1 - p, the draw is a function of (seed, layer, position)
+    only, y = x * multipliers exactly; the attention form gives the same multipliers as the kernels use."""
+    from autodiffusion_amd import train
+    n, p = (64, 1000, 32), 0.1
+    a = train.dropout_mask(n, train.DropSite(p, 77, 3, None), dev)
+    vals = torch.unique(a)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / 0.9) < 1e-6
+    keep = float((a > 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3, keep
+    assert torch.equal(a, train.dropout_mask(n, train.DropSite(p, 77, 3, None), dev))
+    for other in (train.DropSite(p, 78, 3, None), train.DropSite(p, 77, 4, None)):
+        b = train.dropout_mask(n, other, dev)
+        agree = float(((a > 0) == (b > 0)).float().mean())
+        assert abs(agree - 0.82) < 5e-3, agree              # independent draws agree with probability 0.9^2 + 0.1^2
+    # no structure along rows or columns: keep rates per row and per column stay within sampling noise
+    flat = (a > 0).float().reshape(-1, 32)
+    assert float(flat.mean(0).std()) < 3e-3 and abs(float(flat.mean(1).std()) - (0.09 / 32) ** 0.5) < 5e-3
+    x = torch.randn(n, device=dev)
+    assert torch.equal(train.dropout(x, train.DropSite(p, 77, 3, None)), x * a)
+    assert train.dropout(x, None) is x
+    # attention probabilities: out = (softmax(q k^T) * multipliers) v with the multipliers of attention_dropout_mask
+    B, H, Sq, Skv, dh = 2, 4, 37, 150, 16
+    q, k, v = (torch.randn(B, s, H * dh, device=dev) for s in (Sq, Skv, Skv))
+    site = train.DropSite(0.25, 5, 11, None)
+    m = train.attention_dropout_mask(B, H, Sq, Skv, site, dev)
+    assert abs(float((m > 0).float().mean()) - 0.75) < 5e-3
+    o, _ = train.attention_stats(q, k, v, H, drop=site)
+    s = torch.einsum("bihd,bjhd->bhij", q.double().reshape(B, Sq, H, dh), k.double().reshape(B, Skv, H, dh)) * dh ** -0.5
+    want = torch.einsum("bhij,bjhd->bihd", torch.softmax(s, -1) * m.double(), v.double().reshape(B, Skv, H, dh)).reshape(B, Sq, H * dh)
+    assert l2_rel(o, want) < 2e-6
+    o2, _ = train.attention_stats(q, k, v, H, drop=train.DropSite(0.25, 0, 0, m))
+    assert torch.equal(o, o2)
+    with pytest.raises(Exception):
+        train.dropout_mask(n, train.DropSite(1.0, 1, 1, None), dev)
+
+
+@pytest.mark.parametrize("mask_off", [-1, 0, 1])
+def test_attention_backward_with_dropout(dev, mask_off):
+    """dq, dk, dv of softmax -> dropout -> weighted sum against float64 autograd with the same multipliers, for the three mask
+    rules; hash mode and supplied-multiplier mode are the same computation bit for bit."""
+    from autodiffusion_amd import train
+    B, H, Sq, Skv, dh = 2, 4, 45, 45 if mask_off == 0 else 130, 16
+    g = torch.Generator().manual_seed(3)
+    q, k, v, do = (torch.randn(B, s, H * dh, generator=g) for s in (Sq, Skv, Skv, Sq))
+    site = train.DropSite(0.1, 9, 2, None)
+    m = train.attention_dropout_mask(B, H, Sq, Skv, site, dev)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bihd,bjhd->bhij", qd.reshape(B, Sq, H, dh), kd.reshape(B, Skv, H, dh)) * dh ** -0.5
+    if mask_off >= 0:
+        i, j = torch.arange(Sq)[:, None], torch.arange(Skv)[None, :]
+        s = s.masked_fill(~(j <= i + mask_off), float("-inf"))
+    out = torch.einsum("bhij,bjhd->bihd", torch.softmax(s, -1) * m.cpu().double(), vd.reshape(B, Skv, H, dh)).reshape(B, Sq, H * dh)
+    out.backward(do.double())
+    o, stats = train.attention_stats(q.to(dev), k.to(dev), v.to(dev), H, mask_off=mask_off, drop=site)
+    assert l2_rel(o, out.detach()) < 2e-6
+    got = train.attention_bwd(q.to(dev), k.to(dev), v.to(dev), o, do.to(dev), H, mask_off=mask_off, stats=stats, drop=site)
+    errs = [l2_rel(a, b.grad) for a, b in zip(got, (qd, kd, vd))]
+    print("attention_bwd with dropout", mask_off, ["%.1e" % e for e in errs])
+    assert max(errs) < 2e-5
+    again = train.attention_bwd(q.to(dev), k.to(dev), v.to(dev), o, do.to(dev), H, mask_off=mask_off, stats=stats, drop=train.DropSite(0.1, 0, 0, m))
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    nostats = train.attention_bwd(q.to(dev), k.to(dev), v.to(dev), o, do.to(dev), H, mask_off=mask_off, drop=site)
+    assert max(l2_rel(a, b.grad) for a, b in zip(nostats, (qd, kd, vd))) < 2e-5
+
+
+def test_refiner_gradients_with_dropout_match_the_reference(dev, golden):
+    """The whole refiner in training mode (p_drop_emb = p_drop_attn = 0.1): loss and all 108 gradients against the reference's
+    backward() recorded with the same dropout multipliers (34 layers' worth, in the order the reference draws them)."""
+    from autodiffusion_amd import refiner, synth, train
+    g = golden("g19_dropout_grads")
+    tr = refiner.TrajectoryRefiner(refiner.refiner_config(frame_stack=10, diffusion_timesteps=100, objective="pred_noise", beta_schedule="cosine"))
+    synth.fill_module_(tr, WSEED)
+    tr = tr.to(dev).train()
+    c = _g14_inputs(dev)
+    drawn = []
+    seeded = _seeded_multipliers(dev, DSEED)
+    train.set_dropout(tr.diffusion.model, masks=lambda k, p, shape: (drawn.append(k), seeded(k, p, shape))[1])
+    loss, _ = tr(c["label"], c["transition"], c["prior"], c["maps"], t=T(g["refiner_t"]).to(dev), noise=c["noise"])
+    assert len(drawn) == int(g["refiner_draws"]) == 34
+    np.testing.assert_allclose(float(loss), float(g["refiner_loss"]), rtol=1e-4)
+    loss.backward()
+    sub = {k.replace("refiner.", "", 1): v for k, v in g.items() if k.startswith(("grad.refiner.", "gradnorm.refiner.", "gradsample.refiner."))}
+    grads = {n: p.grad for n, p in tr.diffusion.model.named_parameters()}
+    assert check_grad_fixture(sub, grads, GATE) == 108
+    # the loss differs from the dropout-free one (the layers are really active), and eval mode is the dropout-free computation
+    assert abs(float(loss) - float(golden("g14_refiner_grads")["loss"])) > 1e-3
+    tr.diffusion.model.eval()
+    loss0, _ = tr(c["label"], c["transition"], c["prior"], c["maps"], t=T(g["refiner_t"]).to(dev), noise=c["noise"])
+    np.testing.assert_allclose(float(loss0), float(golden("g14_refiner_grads")["loss"]), rtol=1e-4)
+
+
+def test_decoder_twin_gradients_with_dropout_match_the_reference(dev, golden):
+    """DiT backbone in training mode: torch's default dropout 0.1 inside each block's encoder layer (8 draws for 2 blocks)."""
+    from autodiffusion_amd import dit, synth, train
+    g = golden("g19_dropout_grads")
+    dec = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "DiT", diffusion_timesteps=10))
+    synth.fill_module_(dec, WSEED)
+    dec = dec.to(dev).train()
+    state = synth.hidden_state(2, 64, ISEED).to(dev).requires_grad_(True)
+    label = (synth.trajectory_prior(2, ISEED) + synth.noise(2, (), (80, 4), NSEED + 1) * torch.tensor([1.5, 0.4, 0.0, 0.05])).to(dev)
+    drawn = []
+    seeded = _seeded_multipliers(dev, DSEED + 1)
+    train.set_dropout(dec.model.model, masks=lambda k, p, shape: (drawn.append(k), seeded(k, p, shape))[1])
+    loss, _ = dec(label, state, t=T(g["twin_t"]).to(dev), noise=synth.noise(2, (), (80, 4), NSEED + 2).to(dev))
+    assert len(drawn) == int(g["twin_draws"]) == 8
+    np.testing.assert_allclose(float(loss.detach()), float(g["twin_loss"]), rtol=1e-4)
+    loss.backward()
+    sub = {k.replace("twin.", "", 1): v for k, v in g.items() if k.startswith(("grad.twin.", "gradnorm.twin.", "gradsample.twin."))}
+    grads = {n: p.grad for n, p in dec.model.model.named_parameters() if p.grad is not None}
+    assert check_grad_fixture(sub, grads, GATE) > 60
+    assert l2_rel(state.grad, g["twin_grad_state"]) < GATE
+
+
+def test_hash_dropout_is_the_mask_computation(dev):
+    """A training step that draws from the device hash equals, bit for bit, the step that is handed the multipliers the hash gives:
+    forward and backward regenerate the same draws, nothing is stored.  Seeds: same seed -> same gradients, a different seed or no
+    seed (torch's generator) -> different ones, torch.manual_seed makes the unseeded path repeatable."""
+    from autodiffusion_amd import refiner, synth, train
+    tr = refiner.TrajectoryRefiner(refiner.refiner_config(frame_stack=10, diffusion_timesteps=100, objective="pred_noise", beta_schedule="cosine"))
+    synth.fill_module_(tr, WSEED)
+    tr = tr.to(dev).train()
+    net = tr.diffusion.model
+    c = _g14_inputs(dev)
+    t = torch.tensor([37, 81], device=dev)
+
+    def step(**how):
+        net.zero_grad()
+        if how:
+            train.set_dropout(net, **how)
+        loss, _ = tr(c["label"], c["transition"], c["prior"], c["maps"], t=t, noise=c["noise"])
+        loss.backward()
+        return float(loss), {n: p.grad.clone() for n, p in net.named_parameters()}
+    l1, g1 = step(seed=123)
+    log = []
+    l2, g2 = step(masks=_hash_multipliers(dev, 123, log))
+    assert len(log) == 34 and l1 == l2 and all(torch.equal(g1[n], g2[n]) for n in g1)
+    for m in log:                                   # every layer keeps 90 % of its elements, within 5 sigma of a binomial draw
+        assert abs(float((m > 0).float().mean()) - 0.9) < 5 * (0.09 / m.numel()) ** 0.5 + 1e-4, tuple(m.shape)
+    l3, g3 = step(seed=123)
+    assert l3 == l1 and all(torch.equal(g1[n], g3[n]) for n in g1)
+    l4, _ = step(seed=124)
+    assert l4 != l1
+    torch.manual_seed(5)
+    l5, _ = step()
+    l6, _ = step()
+    torch.manual_seed(5)
+    l7, _ = step()
+    assert l5 != l6 and l5 == l7
