@@ -32,7 +32,7 @@ EXPORTS = [
     "adx_op_linear_noalloc", "adx_noalloc_scratch_bytes", "adx_noalloc_init",
     "adx_op_add", "adx_op_mul", "adx_op_act", "adx_op_act_bwd", "adx_op_group_colsum", "adx_op_transpose", "adx_op_gelu", "adx_op_gelu_bwd", "adx_reduce_ws_bytes", "adx_op_linear_wgrad", "adx_op_colsum",
     "adx_op_layernorm_bwd", "adx_op_attention_bwd", "adx_op_attention_stats", "adx_op_weighted_mse_bwd",
-    "adx_op_raster_patches", "adx_generate_transition",
+    "adx_op_raster_patches", "adx_generate_transition", "adx_op_traj_loss",
     "adx_op_dropout", "adx_op_attention_stats_dropout", "adx_op_attention_bwd_dropout", "adx_op_attention_dropout_mask",
 ]
 
@@ -124,6 +124,7 @@ def load() -> C.CDLL:
         "adx_op_attention_bwd": ([p, p, p, p, p, i, i, i, i, i, f, i, p, p, p, p, i, p], i),
         "adx_op_attention_stats": ([p, p, p, p, p, i, i, i, i, i, f, i, p], i),
         "adx_op_weighted_mse_bwd": ([p, p, p, p, p, p, i, i, p], i),
+        "adx_op_traj_loss": ([p, p, i, i, i, i, i, p, p, p], i),
         "adx_op_raster_patches": ([p, i, i, i, i, i, i, p, p], i),
         "adx_generate_transition": ([p, i, i, i, p, p, p, p, i, p, p, u, p], i),
         "adx_op_dropout": ([p, p, i64, f, C.c_uint64, i, p], i),

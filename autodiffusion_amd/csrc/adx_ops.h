@@ -308,6 +308,8 @@ hipError_t randn_rows(const uint64_t* ctl_dev, float* out, int n_lead, int B, in
 hipError_t q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp, float* xt,
                     float* v, int n_rows, int row_len, hipStream_t stream);
 // loss_rows[b] = weight[t[b]] * mean((out[b] - target[b])^2); loss_mean (optional) = mean over rows.
+hipError_t traj_loss(const float* logits, const float* label, float* part, float* out, int B, int T, int C, int Cl, int smooth_l1,
+                     hipStream_t stream);
 hipError_t weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows, float* loss_mean,
                         int n_rows, int row_len, hipStream_t stream);
 

@@ -569,6 +569,13 @@ ADX_API int adx_op_weighted_mse(const float* out, const float* target, const int
     return done(weighted_mse(out, target, t, weight, loss_rows, loss_mean, n_rows, row_len, (hipStream_t)stream), "weighted_mse");
 }
 
+ADX_API int adx_op_traj_loss(const float* logits, const float* label, int B, int T, int C, int C_label, int smooth_l1, float* part, float* out,
+                             void* stream) {
+    if (!logits || !label || !part || !out) return fail(ADX_EINVAL, "traj_loss: null pointer");
+    if (B <= 0 || T <= 0 || C < 2 || C_label < 2) return fail(ADX_EINVAL, "traj_loss: needs B, T > 0 and at least two channels");
+    return done(traj_loss(logits, label, part, out, B, T, C, C_label, smooth_l1 != 0, (hipStream_t)stream), "traj_loss");
+}
+
 ADX_API int adx_engine_reserve(adx_engine* e, int max_batch) {
     if (!e) return fail(ADX_EINVAL, "reserve: null engine");
     return e->reserve(max_batch);

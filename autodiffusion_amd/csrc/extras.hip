@@ -104,6 +104,47 @@ __global__ __launch_bounds__(256) void weighted_mse_kernel(const float* out, con
     if (lane == 0) loss_rows[row] = s / (float)row_len * weight[t[row]];
 }
 
+// The default branch of TrajectoryDecoder.compute_traj_loss (models/decoder/base.py:9-35, 238-241): positions -- the first two
+// channels -- under the squared error or SmoothL1 (beta = 1); heading -- the last channel -- under the squared angular difference,
+// every angle and the difference wrapped into (-pi, pi] by atan2(sin, cos).  One wavefront per batch row; part[b] = {sum of the
+// position terms, sum of the heading terms}, lanes combined in a fixed butterfly order.
+__device__ __forceinline__ float wrap_angle(float a) { return atan2f(sinf(a), cosf(a)); }
+
+__global__ __launch_bounds__(256) void traj_loss_rows_kernel(const float* logits, const float* label, float* part, int B, int T, int C, int Cl,
+                                                              int smooth_l1) {
+    const int row = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float* a = logits + (int64_t)row * T * C;
+    const float* b = label + (int64_t)row * T * Cl;
+    float sxy = 0.f, syaw = 0.f;
+    for (int t = lane; t < T; t += 64) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float d = a[t * C + c] - b[t * Cl + c], ad = fabsf(d);
+            sxy += smooth_l1 ? (ad < 1.f ? 0.5f * d * d : ad - 0.5f) : d * d;
+        }
+        const float d = wrap_angle(wrap_angle(b[t * Cl + Cl - 1]) - wrap_angle(a[t * C + C - 1]));
+        syaw = fmaf(d, d, syaw);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sxy += __shfl_xor(sxy, o, 64); syaw += __shfl_xor(syaw, o, 64); }
+    if (lane == 0) { part[2 * row] = sxy; part[2 * row + 1] = syaw; }
+}
+
+// out[0] = mean position term, out[1] = mean heading term: one workgroup, fixed summation order
+__global__ __launch_bounds__(256) void traj_loss_mean_kernel(const float* part, int B, int T, float* out) {
+    __shared__ float px[256], py[256];
+    float sx = 0.f, sy = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) { sx += part[2 * i]; sy += part[2 * i + 1]; }
+    px[threadIdx.x] = sx; py[threadIdx.x] = sy;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { px[threadIdx.x] += px[threadIdx.x + o]; py[threadIdx.x] += py[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = px[0] / ((float)B * T * 2.f); out[1] = py[0] / ((float)B * T); }
+}
+
 // mean of n values, one workgroup, fixed summation order
 __global__ __launch_bounds__(256) void mean_kernel(const float* x, int n, float* out) {
     __shared__ float part[256];
@@ -153,6 +194,14 @@ hipError_t weighted_mse(const float* out, const float* target, const int64_t* t,
     hipLaunchKernelGGL(weighted_mse_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, stream, out, target, t, weight, loss_rows, n_rows,
                        row_len);
     if (loss_mean) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, loss_rows, n_rows, loss_mean);
+    return hipGetLastError();
+}
+
+hipError_t traj_loss(const float* logits, const float* label, float* part, float* out, int B, int T, int C, int Cl, int smooth_l1,
+                     hipStream_t stream) {
+    if (B <= 0 || T <= 0 || C < 2 || Cl < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(traj_loss_rows_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, logits, label, part, B, T, C, Cl, smooth_l1);
+    hipLaunchKernelGGL(traj_loss_mean_kernel, dim3(1), dim3(256), 0, stream, part, B, T, out);
     return hipGetLastError();
 }
 

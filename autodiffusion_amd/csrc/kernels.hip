@@ -363,6 +363,42 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs 
     }
 }
 
+// Narrow rows (d = 4 * LANES floats, LANES = 8, 16 or 32; 16-byte aligned operands): LANES lanes per row, one float4 each, a
+// wave takes 64 / LANES consecutive rows, so a wave's load is still one contiguous 1 KB piece (the wave-per-row form above reads
+// 128 bytes per wave for d = 32 and leaves most lanes idle).
+template <int LANES>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const LayerNormArgs a) {
+    constexpr int RPW = 64 / LANES;
+    const int lane = threadIdx.x & 63, ql = lane & (LANES - 1);
+    const int row_raw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LANES;
+    const bool live = row_raw < a.rows;
+    const int row = live ? row_raw : a.rows - 1;
+    float4 v = reinterpret_cast<const float4*>(a.x + map_row(a.xmap, row) * a.ldx)[ql];
+    auto group_sum = [](float t) {
+#pragma unroll
+        for (int o = LANES / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    const float inv_d = 1.0f / (4.0f * LANES);
+    const float mean = group_sum((v.x + v.y) + (v.z + v.w)) * inv_d;
+    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+    const float rstd = rsqrt_fast(group_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * inv_d + a.eps);
+    const int64_t mrow = a.mod_group ? (int64_t)(row / a.mod_group) * a.mod_period + row % a.mod_period : (int64_t)row;
+    float o[4] = {v.x * rstd, v.y * rstd, v.z * rstd, v.w * rstd};
+    if (a.gamma) {
+        const float4 g = reinterpret_cast<const float4*>(a.gamma)[ql], b = reinterpret_cast<const float4*>(a.beta)[ql];
+        o[0] = fmaf(o[0], g.x, b.x); o[1] = fmaf(o[1], g.y, b.y); o[2] = fmaf(o[2], g.z, b.z); o[3] = fmaf(o[3], g.w, b.w);
+    }
+    if (a.scale) {
+        const float4 k = reinterpret_cast<const float4*>(a.scale + mrow * a.ldm)[ql], h = reinterpret_cast<const float4*>(a.shift + mrow * a.ldm)[ql];
+        o[0] = fmaf(o[0], 1.f + k.x, h.x); o[1] = fmaf(o[1], 1.f + k.y, h.y); o[2] = fmaf(o[2], 1.f + k.z, h.z); o[3] = fmaf(o[3], 1.f + k.w, h.w);
+    }
+    if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+    if (a.gate) { const float4 g = reinterpret_cast<const float4*>(a.gate + mrow * a.ldg)[ql]; o[0] *= g.x; o[1] *= g.y; o[2] *= g.z; o[3] *= g.w; }
+    if (a.res) { const float4 r = reinterpret_cast<const float4*>(a.res + (int64_t)row * a.ldr)[ql]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
+    if (live) reinterpret_cast<float4*>(a.y + map_row(a.ymap, row) * a.ldy)[ql] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // The form for results that go out as operand planes [d/16][rows][16]: a QUARTER wave (16 lanes) per row, a wave takes four
 // consecutive rows, a lane keeps NQ = d/64 float4 of its row.  The four lanes that share a 16-column block of a row write its
 // 32 bytes, and the four quarters write four consecutive rows of that block: one store instruction covers whole 128-byte
@@ -429,12 +465,16 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const LayerNormAr
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static bool layernorm_operands_aligned(const LayerNormArgs& a) {
+    return (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && aligned16(a.x) && aligned16(a.y) &&
+           (!a.gamma || (aligned16(a.gamma) && aligned16(a.beta))) &&
+           (!a.shift || ((a.ldm & 3) == 0 && aligned16(a.shift) && aligned16(a.scale))) &&
+           (!a.gate || ((a.ldg & 3) == 0 && aligned16(a.gate))) && (!a.res || ((a.ldr & 3) == 0 && aligned16(a.res)));
+}
+
 hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
     if (a.rows <= 0 || a.d <= 0) return hipErrorInvalidValue;
-    const bool vec = (a.d % 256) == 0 && (a.ldx & 3) == 0 && (a.ldy & 3) == 0 && aligned16(a.x) && aligned16(a.y) &&
-                     (!a.gamma || (aligned16(a.gamma) && aligned16(a.beta))) &&
-                     (!a.shift || ((a.ldm & 3) == 0 && aligned16(a.shift) && aligned16(a.scale))) &&
-                     (!a.gate || ((a.ldg & 3) == 0 && aligned16(a.gate))) && (!a.res || ((a.ldr & 3) == 0 && aligned16(a.res)));
+    const bool vec = (a.d % 256) == 0 && layernorm_operands_aligned(a);
     const dim3 grid((a.rows + 3) / 4), block(256);
     if (a.ph && (!vec || a.ymap.per_batch != 0)) return hipErrorInvalidValue;       // planes come from the register-resident kernel only
     if (!a.y && !a.ph) return hipErrorInvalidValue;
@@ -464,6 +504,14 @@ hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream) {
         }
     }
     if (a.ph || !a.y) return hipErrorInvalidValue;
+    if ((a.d == 32 || a.d == 64 || a.d == 128) && layernorm_operands_aligned(a)) {
+        const int lanes = a.d / 4, rpw = 64 / lanes;
+        const dim3 ngrid((a.rows + 4 * rpw - 1) / (4 * rpw));
+        if (lanes == 8) hipLaunchKernelGGL(layernorm_narrow_kernel<8>, ngrid, block, 0, stream, a);
+        else if (lanes == 16) hipLaunchKernelGGL(layernorm_narrow_kernel<16>, ngrid, block, 0, stream, a);
+        else hipLaunchKernelGGL(layernorm_narrow_kernel<32>, ngrid, block, 0, stream, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, stream, a);
     return hipGetLastError();
 }

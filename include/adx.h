@@ -228,6 +228,13 @@ int adx_op_q_sample(const float* x0, const float* noise, const int64_t* t, const
 int adx_op_weighted_mse(const float* out, const float* target, const int64_t* t, const float* weight, float* loss_rows,
                         float* loss_mean, int n_rows, int row_len, void* stream);
 
+/* The default branch of TrajectoryDecoder.compute_traj_loss (models/decoder/base.py:9-35, 238-241): logits[B][T][C], label[B][T][C_label];
+ * out[0] = mean over (b, t, first two channels) of the squared error (smooth_l1 = 0) or SmoothL1 with beta 1; out[1] = mean over
+ * (b, t) of the squared difference of the LAST channels as angles, each angle and the difference wrapped by atan2(sin, cos).
+ * part[B][2] receives the per-row sums. */
+int adx_op_traj_loss(const float* logits, const float* label, int B, int T, int C, int C_label, int smooth_l1, float* part, float* out,
+                     void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Conditioning producer, first stage (phase 1 of generate(): NuplanRasterizeEncoder.forward,
  * models/encoder/nuplan_raster_encoder.py:178-187, with cat_raster_seq, models/utils.py:14-41, and the Conv2d patch embedding

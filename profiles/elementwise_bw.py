@@ -41,7 +41,8 @@ def timed(name, fn, nbytes, iters=20):
 print(f"{'kernel (entry point, shape)':78s} {'bytes':>12s} {'time':>12s} {'achieved':>13s}  of 8 TB/s")
 lib = _lib.load()
 # ---- LayerNorm family: rows of d floats, read once, written once (+ shift / scale rows read once with adaLN modulation)
-for d, tag in ((1024, "layernorm_vec_kernel<4>"), (256, "layernorm_vec_kernel<1>"), (2048, "layernorm_vec_kernel<8>"), (32, "layernorm_kernel (wave per row)")):
+for d, tag in ((1024, "layernorm_vec_kernel<4>"), (256, "layernorm_vec_kernel<1>"), (2048, "layernorm_vec_kernel<8>"), (128, "layernorm_narrow_kernel<32>"),
+               (32, "layernorm_narrow_kernel<8>"), (96, "layernorm_kernel (wave per row, any width)")):
     n = R if d >= 256 else R * 8
     n = min(n, (3 << 30) // (d * 4))
     x = torch.randn(n, d, device=dev)

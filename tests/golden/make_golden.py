@@ -764,8 +764,42 @@ def g18_raster_encoder():
         print(f"g18 {tag}: maps_info rms {float(maps.pow(2).mean().sqrt()):.3f}, input_embeds {tuple(embeds.shape)}, context_length {info['context_length']}")
     save("g18_raster_encoder", **out)
 
+# ----------------------------------------------------------------------------- G20: the head that produces the trajectory prior
+def g20_trajectory_decoder():
+    """The reference's TrajectoryDecoder (models/decoder/base.py:42-260), both heads (DecoderResCat with n_inner 1024, and a single
+    Linear), n_embd 256, seeded weights; hidden states (2, 868, 256) seeded; labels with headings pushed beyond +-pi so that the
+    wrapping matters.  Stored: generate_trajs, and compute_traj_loss for both slices (context_length given with 5 selected key
+    points / not given), both loss functions, with and without the heading term, rescale 2.5."""
+    from transformer4planning.models.decoder.base import TrajectoryDecoder
+    out = {}
+    B = 2
+    hidden = synth.noise(B, (), (868, 256), NSEED + 20)
+    label = synth.trajectory_prior(B, ISEED) + synth.noise(B, (), (80, 4), NSEED + 21) * torch.tensor([1.5, 0.4, 0.0, 2.5])
+    out["label"] = label
+    for kind in ("mlp", "linear"):
+        for loss_fn in ("mse", "l1"):
+            cfg = SimpleNamespace(n_embd=256, n_inner=1024, trajectory_decoder_type=kind, predict_yaw=True, loss_fn=loss_fn, traj_dropout=0.0,
+                                  task="nuplan", mean_circular_loss=True, trajectory_prediction_mode="all_frames", pred_key_points_only=False,
+                                  trajectory_loss_rescale=2.5, first_frame_scele=1.0)
+            dec = TrajectoryDecoder(cfg)
+            synth.fill_module_(dec, WSEED)
+            dec = dec.float().eval()
+            with torch.no_grad():
+                if loss_fn == "mse":
+                    out[f"{kind}_trajs"] = dec.generate_trajs(hidden, {"pred_length": 80})
+                tail, _ = dec.compute_traj_loss(hidden, label, {"pred_length": 80})
+                ctx, logits = dec.compute_traj_loss(hidden, label, {"pred_length": 80, "context_length": 700, "selected_indices": [79, 39, 19, 9, 4]})
+                noyaw, _ = dec.compute_traj_loss(hidden, label, {"pred_length": 80, "context_length": 788}, no_yaw_loss=True)
+            out[f"{kind}_{loss_fn}_loss_tail"], out[f"{kind}_{loss_fn}_loss_ctx"], out[f"{kind}_{loss_fn}_loss_noyaw"] = tail, ctx, noyaw
+            if loss_fn == "mse":
+                out[f"{kind}_logits_ctx"] = logits
+            print(f"g20 {kind} {loss_fn}: losses {float(tail):.4f} {float(ctx):.4f} {float(noyaw):.4f}")
+    save("g20_trajectory_decoder", **out)
+
+
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
-       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop, "g18": g18_raster_encoder, "g19": g19_dropout_grads}
+       "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop, "g18": g18_raster_encoder, "g19": g19_dropout_grads,
+       "g20": g20_trajectory_decoder}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

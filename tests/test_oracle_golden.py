@@ -570,3 +570,34 @@ def test_raster_encoder(golden):
     sd = raster_encoder_sd(256, 8, 3072, False)
     maps = raster.raster_maps_info(sd, synth.occupancy_raster(1, 58, ISEED), synth.occupancy_raster(1, 58, ISEED + 1), T(g["full_context_actions"]), 8)
     assert rel_err(maps[:, ::7], g["full_maps_info_every7"]) < 1e-4
+
+
+def trajectory_decoder_sd(kind, n_embd=256, n_inner=1024):
+    if kind == "linear":
+        shapes = [("model.weight", (4, n_embd)), ("model.bias", (4,))]
+    else:
+        shapes = [("model.mlp.linear.weight", (n_inner, n_embd)), ("model.mlp.linear.bias", (n_inner,)), ("model.mlp.layer_norm.weight", (n_inner,)),
+                  ("model.mlp.layer_norm.bias", (n_inner,)), ("model.fc.weight", (4, n_inner + n_embd)), ("model.fc.bias", (4,))]
+    return synth.seeded_state(shapes, WSEED)
+
+
+@pytest.mark.parametrize("kind", ["mlp", "linear"])
+def test_trajectory_decoder(golden, kind):
+    """The oracle's TrajectoryDecoder against the recording of the reference's: the prior it generates, and the loss for both
+    hidden-state slices, both loss functions, with and without the heading term."""
+    from oracle import trajectory_decoder as td
+    g = golden("g20_trajectory_decoder")
+    sd = trajectory_decoder_sd(kind)
+    hidden, label = synth.noise(2, (), (868, 256), NSEED + 20), T(g["label"])
+    assert rel_err(td.generate_trajs(sd, hidden, 80, kind), g[f"{kind}_trajs"]) < 1e-5
+    for loss_fn in ("mse", "l1"):
+        tail, _ = td.compute_traj_loss(sd, hidden, label, 80, kind=kind, loss_fn=loss_fn, rescale=2.5)
+        ctx, logits = td.compute_traj_loss(sd, hidden, label, 80, 700, [79, 39, 19, 9, 4], kind=kind, loss_fn=loss_fn, rescale=2.5)
+        noyaw, _ = td.compute_traj_loss(sd, hidden, label, 80, 788, kind=kind, loss_fn=loss_fn, no_yaw_loss=True, rescale=2.5)
+        for got, key in ((tail, "tail"), (ctx, "ctx"), (noyaw, "noyaw")):
+            np.testing.assert_allclose(float(got), float(g[f"{kind}_{loss_fn}_loss_{key}"]), rtol=1e-5)
+        if loss_fn == "mse":
+            assert rel_err(logits, g[f"{kind}_logits_ctx"]) < 1e-5
+    # headings a whole turn apart are the same heading
+    a = torch.tensor([0.3, -2.0, 3.0])
+    assert float(td.mean_circular_error(a + 2 * np.pi, a)) < 1e-10 and abs(float(td.mean_circular_error(a, a + 4.0)) - (2 * np.pi - 4.0) ** 2) < 1e-4
