@@ -15,15 +15,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADX_LIB_PATH") or os.path.join(_HERE, "libadx.so")      # ADX_LIB_PATH: another build of the library (same-box A/B timings)
 
 ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY, ACT_SILU, ACT_TANH = range(7)     # ACT_TANH: adx_op_act only
-PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_F16X2, PREC_F16 = 0, 1, 2, 3, 4
+PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "f16x2": PREC_F16X2, "f16": PREC_F16}
 VARIANT_A, VARIANT_DIT, VARIANT_MMDIT = 0, 1, 2
 FLAG_NORMALIZE, FLAG_RESIDUAL, FLAG_INIT_ZERO, FLAG_NO_GRAPH, FLAG_KEEP_MAPS = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "adx_abi_version", "adx_last_error",
     "adx_op_timestep_embedding", "adx_op_linear", "adx_op_linear_staged", "adx_linear_stage_bytes", "adx_linear_planes_bytes", "adx_op_stage_planes", "adx_op_block_weight",
-    "adx_op_linear_planes", "adx_op_mlp256", "adx_op_to_bf16", "adx_op_layernorm", "adx_op_attention", "adx_op_attention_prec",
+    "adx_op_linear_planes", "adx_op_mlp256", "adx_op_to_bf16", "adx_op_to_f16", "adx_op_layernorm", "adx_op_attention", "adx_op_attention_prec",
     "adx_op_normalize", "adx_op_denormalize", "adx_op_sched_step",
     "adx_engine_create", "adx_engine_destroy", "adx_engine_set_tensor", "adx_engine_finalize", "adx_engine_reserve",
     "adx_engine_workspace_bytes", "adx_denoise_a", "adx_denoise_dit", "adx_engine_set_schedule", "adx_sample_a",
@@ -76,6 +76,7 @@ def load() -> C.CDLL:
         "adx_op_block_weight": ([p, i, i, i, p, p], i),
         "adx_op_linear_planes": ([p, p, p, p, i, i, i, i, i, p], i),
         "adx_op_to_bf16": ([p, p, i64, p], i),
+        "adx_op_to_f16": ([p, p, i64, p], i),
         "adx_op_layernorm": ([p, p, p, p, p, i64, f, i, i64, i, p, p], i),
         "adx_op_mlp256": ([p, p, p, i, p, p, i, p, p, p, i, i, i, p], i),
         "adx_op_attention_prec": ([p, p, p, p, i, i, i, i, i, i, f, i, i, p], i),

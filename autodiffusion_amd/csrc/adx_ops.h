@@ -48,12 +48,17 @@ struct LinearArgs {
     // Also store the result as K-blocked planes of the NEXT product's operand, [N/16][M][16] (Yl may be null: high halves only);
     // Y may then be null (planes only).  Large-tile kernels only (linear_big_ok), 16-byte epilogue, no column map.
     unsigned short* Yh = nullptr; unsigned short* Yl = nullptr;
+    // Planes this call reads or writes hold fp16 instead of bf16 halves, and a product whose X arrives as planes is an fp16
+    // product with W rounded once to fp16, K-blocked in Wblk_h: x_hi w + x_lo w when Xl is given, x_hi w alone otherwise.  A call
+    // whose X is fp32 runs as its `prec` says and only its output planes change format.
+    bool f16 = false; const void* Wblk_h = nullptr;
 };
 // A call with pre-staged X planes (and a pre-blocked or stageable W) takes the staged kernel: bf16 precisions, K a multiple of 32,
 // enough 256 x 128 tiles to fill the chip.
 bool linear_planes_ok(int M, int N, int K, int prec);
 // x[M][K] (row stride ldx, optional SiLU) -> K-blocked planes [K/16][M][16]: hi = bf16(x), lo (nullable) = bf16(x - hi).
-hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream);
+hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream,
+                        bool f16 = false);      // f16: fp16 halves (saturating) instead of bf16 ones
 size_t linear_stage_bytes(int M, int N, int K, int prec);
 hipError_t linear_staged_prepare();          // one-time, non-stream set-up of the staged product's kernels (call outside graph capture)
 hipError_t linear_block_weight(const void* w, int N, int K, void* out, hipStream_t stream);   // [N][K] bf16 -> [K/16][N][16]
@@ -83,6 +88,7 @@ struct LayerNormArgs {
     // also (or, with y == nullptr, only) store the result as K-blocked bf16 planes [d/16][rows][16] for a following product:
     // ph = bf16(v), pl (nullable) = bf16(v - ph).  d a multiple of 256 (the register-resident kernel), identity row order.
     unsigned short* ph = nullptr; unsigned short* pl = nullptr;
+    bool pf16 = false;                  // the planes hold fp16 halves (saturating) instead of bf16 ones
 };
 hipError_t layernorm(const LayerNormArgs& a, hipStream_t stream);
 
@@ -315,6 +321,7 @@ hipError_t weighted_mse(const float* out, const float* target, const int64_t* t,
 
 // f32 -> bf16 (round to nearest even); ylo (optional) receives bf16(x - bf16(x))
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream);
+hipError_t to_f16(const float* x, uint16_t* y, int64_t n, hipStream_t stream);      // fp16 bits, saturating
 // strided 2-D copy: dst[r * ldd + c] = src[(r % src_rows) * lds + c]   (src_rows <= 0: no wrap; wrap = broadcast)
 hipError_t copy2d(const float* src, int64_t lds, int64_t src_rows, float* dst, int64_t ldd, int64_t rows, int cols,
                   hipStream_t stream);

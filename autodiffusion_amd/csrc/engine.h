@@ -31,6 +31,7 @@ struct Param {
     uint16_t* bf16lo = nullptr;   // bf16(w - bf16(w)), for the split-operand GEMM
     uint16_t* blk = nullptr;      // the same two planes in the K-blocked layout [K/16][N][16] the staged GEMM copies from (built by
     uint16_t* blk_lo = nullptr;   // finalize() for engines that ask for it), so that no call re-lays the weights
+    uint16_t* blk_h = nullptr;    // the weight rounded once to fp16 in the same K-blocked layout (engines created with ADX_PREC_F16X2)
     std::vector<int64_t> shape;
     int64_t numel = 0;
 };
@@ -45,6 +46,9 @@ struct ParamSpec {
 // The opaque handle of the C ABI.
 struct adx_engine {
     adx_model_config cfg{};
+    bool f16x2 = false;              // created with ADX_PREC_F16X2: cfg.precision reads ADX_PREC_BF16X3 (what every kernel but the
+                                     // operand-plane products runs as), planes hold fp16 halves and those products take two terms
+    bool f16_single = false;         // created with ADX_PREC_F16: as f16x2, but the planes hold high halves only (one term per product)
     int device = 0;
     bool finalized = false;
     std::map<std::string, adx::Param> params;

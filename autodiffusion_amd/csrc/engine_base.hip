@@ -37,6 +37,7 @@ adx_engine::~adx_engine() {
         if (kv.second.bf16lo) (void)hipFree(kv.second.bf16lo);
         if (kv.second.blk) (void)hipFree(kv.second.blk);
         if (kv.second.blk_lo) (void)hipFree(kv.second.blk_lo);
+        if (kv.second.blk_h) (void)hipFree(kv.second.blk_h);
     }
     if (ws) (void)hipFree(ws);
     if (stage_buf) (void)hipFree(stage_buf);
@@ -90,6 +91,7 @@ LinearArgs adx_engine::lin(const float* X, int64_t ldx, const std::string& wname
     if (prec != ADX_PREC_F32) {
         const Param* p = find(wname);
         if (p && p->blk && row0 == 0 && p->shape.size() == 2 && N == p->shape[0] && K == p->shape[1]) { a.Wblk = p->blk; a.Wblk_lo = p->blk_lo; }
+        if (f16x2 && prec == ADX_PREC_BF16X3) { a.f16 = true; a.Wblk_h = a.Wblk ? p->blk_h : nullptr; }
     }
     return a;
 }
@@ -110,7 +112,8 @@ int adx_engine::set_tensor(const char* name, const float* data, const int64_t* s
         if (p.bf16lo) (void)hipFree(p.bf16lo);
         if (p.blk) (void)hipFree(p.blk);
         if (p.blk_lo) (void)hipFree(p.blk_lo);
-        p.f32 = nullptr; p.bf16 = nullptr; p.bf16lo = nullptr; p.blk = nullptr; p.blk_lo = nullptr;
+        if (p.blk_h) (void)hipFree(p.blk_h);
+        p.f32 = nullptr; p.bf16 = nullptr; p.bf16lo = nullptr; p.blk = nullptr; p.blk_lo = nullptr; p.blk_h = nullptr;
         ADX_HIP(hipMalloc(&p.f32, sizeof(float) * numel));
         if (ndim >= 2) {
             ADX_HIP(hipMalloc(&p.bf16, sizeof(uint16_t) * numel));
@@ -150,6 +153,16 @@ int adx_engine::finalize() {
             }
             ADX_HIP(linear_block_weight(p.bf16, (int)N, (int)K, p.blk, nullptr));
             ADX_HIP(linear_block_weight(p.bf16lo, (int)N, (int)K, p.blk_lo, nullptr));
+            if (f16x2) {                    // fp16 copy, K-blocked: row-major fp16 bits through a scratch buffer first
+                uint16_t* tmp = nullptr;
+                if (!p.blk_h) ADX_HIP(hipMalloc(&p.blk_h, sizeof(uint16_t) * p.numel));
+                ADX_HIP(hipMalloc(&tmp, sizeof(uint16_t) * p.numel));
+                hipError_t e = to_f16(p.f32, tmp, p.numel, nullptr);
+                if (e == hipSuccess) e = linear_block_weight(tmp, (int)N, (int)K, p.blk_h, nullptr);
+                if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+                (void)hipFree(tmp);
+                ADX_HIP(e);
+            }
         }
     }
     ADX_HIP(hipStreamSynchronize(nullptr));
@@ -352,20 +365,26 @@ ADX_API size_t adx_linear_stage_bytes(int M, int N, int K, int prec) { return li
 // Operands kept in the staged kernel's own layout across calls: K-blocked bf16 planes [K/16][rows][16], the high-half plane
 // followed by the low-half plane under ADX_PREC_BF16X3.  A caller that multiplies the same X or W more than once (or whose
 // producer can write the planes) pays the re-layout once and then launches the product kernel alone.
-ADX_API size_t adx_linear_planes_bytes(int rows, int K, int prec) { return (size_t)rows * K * 2 * (prec == ADX_PREC_BF16X3 ? 2 : 1); }
+ADX_API size_t adx_linear_planes_bytes(int rows, int K, int prec) {
+    return (size_t)rows * K * 2 * ((prec == ADX_PREC_BF16X3 || prec == ADX_PREC_F16X2) ? 2 : 1);       // ADX_PREC_F16: one plane
+}
 
 ADX_API int adx_op_stage_planes(const float* x, int M, int K, int prec, void* planes, void* stream) {
     if (!x || !planes) return fail(ADX_EINVAL, "stage_planes: null pointer");
-    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "stage_planes: bf16 precisions only");
+    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3 && prec != ADX_PREC_F16X2 && prec != ADX_PREC_F16)
+        return fail(ADX_EINVAL, "stage_planes: bf16 / fp16 precisions only");
     if (M <= 0 || K <= 0 || (K % 16) != 0 || (reinterpret_cast<uintptr_t>(planes) & 15) || (reinterpret_cast<uintptr_t>(x) & 15))
         return fail(ADX_EINVAL, "stage_planes: K must be a multiple of 16 and both pointers 16-byte aligned");
     unsigned short* hi = reinterpret_cast<unsigned short*>(planes);
-    return done(stage_planes(x, K, M, K, ACT_NONE, hi, prec == ADX_PREC_BF16X3 ? hi + (size_t)M * K : nullptr, (hipStream_t)stream), "stage_planes");
+    const bool two = prec == ADX_PREC_BF16X3 || prec == ADX_PREC_F16X2;
+    return done(stage_planes(x, K, M, K, ACT_NONE, hi, two ? hi + (size_t)M * K : nullptr, (hipStream_t)stream,
+                             prec == ADX_PREC_F16X2 || prec == ADX_PREC_F16), "stage_planes");
 }
 
 ADX_API int adx_op_block_weight(const void* w, int N, int K, int prec, void* blocked, void* stream) {
     if (!w || !blocked) return fail(ADX_EINVAL, "block_weight: null pointer");
-    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3) return fail(ADX_EINVAL, "block_weight: bf16 precisions only");
+    if (prec != ADX_PREC_BF16 && prec != ADX_PREC_BF16X3 && prec != ADX_PREC_F16X2 && prec != ADX_PREC_F16)
+        return fail(ADX_EINVAL, "block_weight: bf16 / fp16 precisions only");
     if (N <= 0 || K <= 0 || (K % 32) != 0 || (reinterpret_cast<uintptr_t>(blocked) & 15) || (reinterpret_cast<uintptr_t>(w) & 15))
         return fail(ADX_EINVAL, "block_weight: K must be a multiple of 32 and both pointers 16-byte aligned");
     const uint16_t* src = reinterpret_cast<const uint16_t*>(w);
@@ -378,8 +397,10 @@ ADX_API int adx_op_block_weight(const void* w, int N, int K, int prec, void* blo
 ADX_API int adx_op_linear_planes(const void* x_planes, const void* w_blocked, const float* bias, float* y, int M, int N, int K, int act,
                                  int prec, void* stream) {
     if (!x_planes || !w_blocked || !y) return fail(ADX_EINVAL, "linear_planes: null pointer");
+    const bool f16 = prec == ADX_PREC_F16X2 || prec == ADX_PREC_F16;
+    if (f16) prec = prec == ADX_PREC_F16X2 ? ADX_PREC_BF16X3 : ADX_PREC_BF16;      // the fp16 forms are instances of the split / single-pass kernels
     if (!linear_planes_ok(M, N, K, prec))
-        return fail(ADX_EINVAL, "linear_planes: needs a bf16 precision, M >= 256, N >= 64 and a multiple of 4, K >= 512 and a multiple of 64, "
+        return fail(ADX_EINVAL, "linear_planes: needs a bf16 / fp16 precision, M >= 256, N >= 64 and a multiple of 4, K >= 512 and a multiple of 64, "
                                 "and at least 320 tiles of 256 x 128");
     if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(w_blocked) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
         (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
@@ -389,6 +410,7 @@ ADX_API int adx_op_linear_planes(const void* x_planes, const void* w_blocked, co
     const uint16_t* wh = reinterpret_cast<const uint16_t*>(w_blocked);
     a.Xh = xh; a.Wblk = wh; a.W = wh;                  // W / Wlo only satisfy the shape checks: with both operands staged nothing reads them
     if (prec == ADX_PREC_BF16X3) { a.Xl = xh + (size_t)M * K; a.Wblk_lo = wh + (size_t)N * K; a.Wlo = a.Wblk_lo; }
+    if (f16) { a.f16 = true; a.Wblk_h = wh; a.Wblk_lo = nullptr; a.Wlo = wh; }     // one fp16 plane of W (X: two planes or one)
     a.ldx = K; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
     return done(linear(a, (hipStream_t)stream), "linear_planes");
 }
@@ -427,6 +449,11 @@ ADX_API int adx_op_trajectory_metrics(const float* pred, const float* label, int
     if (!pred || !label || !out) return fail(ADX_EINVAL, "trajectory_metrics: null pointer");
     if (S <= 0 || S > 80 || (80 % S) != 0 || (C != 2 && C != 4)) return fail(ADX_EINVAL, "trajectory_metrics: S must divide 80 and C be 2 or 4");
     return done(trajectory_metrics(pred, label, B, S, C, out, (hipStream_t)stream), "trajectory_metrics");
+}
+
+ADX_API int adx_op_to_f16(const float* x, uint16_t* y, int64_t n, void* stream) {
+    if (!x || !y) return fail(ADX_EINVAL, "to_f16: null pointer");
+    return done(to_f16(x, y, n, (hipStream_t)stream), "to_f16");
 }
 
 ADX_API int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
@@ -493,8 +520,16 @@ ADX_API int adx_op_sched_step(const float* x, const float* model_out, const floa
 
 ADX_API int adx_engine_create(const adx_model_config* cfg, adx_engine** out) {
     if (!cfg || !out) return fail(ADX_EINVAL, "engine_create: null pointer");
-    if (cfg->precision != ADX_PREC_F32 && cfg->precision != ADX_PREC_BF16 && cfg->precision != ADX_PREC_BF16X3)
+    const bool f16_single = cfg->precision == ADX_PREC_F16;
+    if (cfg->precision != ADX_PREC_F32 && cfg->precision != ADX_PREC_BF16 && cfg->precision != ADX_PREC_BF16X3 && cfg->precision != ADX_PREC_F16X2 &&
+        !f16_single)
         return fail(ADX_EINVAL, "engine_create: unknown precision");
+    if ((cfg->precision == ADX_PREC_F16X2 || f16_single) && cfg->variant != ADX_VARIANT_DIT)
+        return fail(ADX_EINVAL, "engine_create: ADX_PREC_F16X2 / ADX_PREC_F16 are precisions of the DiT engine (its operand-plane products)");
+    adx_model_config base = *cfg;
+    const bool f16x2 = cfg->precision == ADX_PREC_F16X2 || f16_single;
+    if (f16x2) base.precision = ADX_PREC_BF16X3;
+    cfg = &base;
     if (cfg->d_model <= 0 || cfg->n_head <= 0 || cfg->d_model % cfg->n_head) return fail(ADX_EINVAL, "engine_create: d_model must be a positive multiple of n_head");
     if (cfg->horizon <= 0 || cfg->in_dim <= 0 || cfg->out_dim <= 0 || cfg->n_layers <= 0) return fail(ADX_EINVAL, "engine_create: bad dimensions");
     adx_engine* e = nullptr;
@@ -502,6 +537,8 @@ ADX_API int adx_engine_create(const adx_model_config* cfg, adx_engine** out) {
     else if (cfg->variant == ADX_VARIANT_DIT || cfg->variant == ADX_VARIANT_MMDIT) e = make_engine_dit(*cfg);
     else return fail(ADX_EINVAL, "engine_create: unknown variant");
     if (!e) return ADX_EINVAL;   // message set by the factory
+    e->f16x2 = f16x2;
+    e->f16_single = f16_single;
     hipError_t he = hipGetDevice(&e->device);
     if (he != hipSuccess) { delete e; return hip_fail(he, "hipGetDevice"); }
     *out = e;

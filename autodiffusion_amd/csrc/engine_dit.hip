@@ -151,7 +151,7 @@ struct EngineDiT final : adx_engine {
     // and the fp32 concatenation never exists.
     int run_stages(const std::vector<Stage>& st, std::vector<float*>& cat, int R, float* out, const float* pos, hipStream_t s) {
         const int eprec = cfg.precision;
-        const bool x3 = eprec == ADX_PREC_BF16X3;
+        const bool x3 = eprec == ADX_PREC_BF16X3 && !f16_single;     // the planes carry low halves
         const char* pl_env = getenv("ADX_DIT_PLANES");               // read per call: 0 = fp32 activations between all kernels
         const char* st_env = getenv("ADX_DIT_STAGE_PLANES");         // 0 = only these stages keep fp32 concatenations (A/B switch)
         const bool planes_on = eprec != ADX_PREC_F32 && !(pl_env && pl_env[0] == '0') && !(st_env && st_env[0] == '0');
@@ -172,7 +172,7 @@ struct EngineDiT final : adx_engine {
             ADX_HIP(linear(l1, s));
             LayerNormArgs ln;
             ln.x = HT; ln.ldx = g.hidden; ln.y = cat[i] + g.in; ln.ldy = ld;
-            if (pk) { ln.y = nullptr; ln.ph = ph + (size_t)g.in * R; ln.pl = x3 ? pl + (size_t)g.in * R : nullptr; }
+            if (pk) { ln.y = nullptr; ln.ph = ph + (size_t)g.in * R; ln.pl = x3 ? pl + (size_t)g.in * R : nullptr; ln.pf16 = f16x2; }
             ln.gamma = P(g.name + ".mlp.layer_norm.weight"); ln.beta = P(g.name + ".mlp.layer_norm.bias");
             ln.eps = 1e-5f; ln.rows = R; ln.d = g.hidden; ln.relu = 1;
             ADX_HIP(layernorm(ln, s));
@@ -201,7 +201,8 @@ struct EngineDiT final : adx_engine {
     // ph: also (y == nullptr: only) store the result as operand planes of the next product (low halves with split operands)
     void set_planes(LayerNormArgs& a, unsigned short* ph, int R) const {
         a.ph = ph;
-        a.pl = (ph && cfg.precision == ADX_PREC_BF16X3) ? ph + (size_t)R * d : nullptr;
+        a.pl = (ph && cfg.precision == ADX_PREC_BF16X3 && !f16_single) ? ph + (size_t)R * d : nullptr;
+        a.pf16 = f16x2;
     }
 
     // Samples of one scenario share their conditioning: with a sample group G > 1, rows (b G + g) S + tok of the token buffers
@@ -255,10 +256,10 @@ struct EngineDiT final : adx_engine {
             const bool pk_d = planes && linear_planes_ok(R, 3 * d, d, prec) && linear_planes_ok(R, 4 * d, d, prec);
             const bool pk_4d = planes && linear_planes_ok(R, d, 4 * d, prec);
             const bool pk_sil = planes && linear_planes_ok(Rc, 6 * d, d, prec);
-            const bool x3 = prec == ADX_PREC_BF16X3;
+            const bool x3 = prec == ADX_PREC_BF16X3 && !f16_single;      // the planes carry low halves
             auto use_planes = [&](LinearArgs& a, const unsigned short* ph, int K) { a.Xh = ph; a.Xl = x3 ? ph + (size_t)R * K : nullptr; };
             auto out_planes = [&](LinearArgs& a, unsigned short* ph, int N) { a.Y = nullptr; a.Yh = ph; a.Yl = x3 ? ph + (size_t)R * N : nullptr; };
-            if (pk_sil) ADX_HIP(stage_planes(SIL, d, Rc, d, ACT_NONE, SILP, x3 ? SILP + (size_t)Rc * d : nullptr, s));
+            if (pk_sil) ADX_HIP(stage_planes(SIL, d, Rc, d, ACT_NONE, SILP, x3 ? SILP + (size_t)Rc * d : nullptr, s, f16x2));
             for (int i = 0; i < NL; ++i) {
                 const std::string p = "blocks." + std::to_string(i);
                 LinearArgs ada = lin(SIL, d, p + ".adaLN_modulation.1.weight", 0, 6 * d, d, p + ".adaLN_modulation.1.bias", MOD, 6 * d, Rc);

@@ -197,16 +197,9 @@ __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* 
             for (int i = 0; i < RP; ++i) {
                 if (pm[i] < 0) continue;
                 const int64_t o = ((int64_t)(n >> 4) * a.M + pm[i]) * 16 + (n & 15);
-                bf16x4 hi;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hi[e] = (__bf16)v[i][e];
-                *reinterpret_cast<bf16x4*>(a.Yh + o) = hi;
-                if (a.Yl) {
-                    bf16x4 lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(v[i][e] - (float)hi[e]);
-                    *reinterpret_cast<bf16x4*>(a.Yl + o) = lo;
-                }
+                const Halves4 hv = split_halves4(v[i], a.f16);
+                *reinterpret_cast<uint2*>(a.Yh + o) = hv.hi;
+                if (a.Yl) *reinterpret_cast<uint2*>(a.Yl + o) = hv.lo;
             }
         }
     }
@@ -822,11 +815,20 @@ __device__ __forceinline__ void load_frags2(Frags<X3>& f, const unsigned char* s
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool X3, int ABL, int S = 1>
+// F16: the planes hold fp16 values.  With X3, X arrives as high and low halves and W rounded once to fp16: a product is TWO matrix
+// instructions, x_lo w + x_hi w (the slot of the W low halves in the LDS image stays empty).  Without X3 both operands are rounded
+// once to fp16: ONE matrix instruction, the single-pass kernel on another element type.  fp16 carries 11 significant bits against
+// bf16's 8: one rounding costs 2^-12 relative instead of 2^-9.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <bool X3, int ABL, int S = 1, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a, const StagedOperands so, int tiles_n, int n_tiles, int pw) {
     constexpr int STAGE_B = (X3 ? 2 : 1) * (G2_A_B + G2_B_B);                  // 24 KB / 12 KB
     constexpr int R = X3 ? 3 : 6;                                              // 72 KB
-    constexpr int P = X3 ? 6 : 3;                                              // copy instructions per wave per K-step
+    constexpr int P = X3 ? (F16 ? 5 : 6) : 3;                                  // copy instructions per wave per K-step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // R * STAGE_B
     // workgroup -> tile: XCD x (blockIdx % 8) walks a contiguous range of a PANEL order -- column panels of `pw` tiles, inside a
     // panel row by row -- so the ~64 workgroups resident on an XCD at one time form a block of about 8 x 8 tiles: per K-step
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
             constexpr int LO = G2_A_B + G2_B_B;
             dma16_unordered(so.xl + xo + xoff0, st + LO);
             dma16_unordered(so.xl + xo + xoff1, st + LO + 4096);
-            dma16_unordered(so.wl + wo, st + LO + G2_A_B);
+            if constexpr (!F16) dma16_unordered(so.wl + wo, st + LO + G2_A_B);
         }
     };
 
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
         const unsigned short* sxh = so.xh + (size_t)kc * xstep;
         const unsigned short* swh = so.wh + (size_t)kc * wstep;
         const unsigned short* sxl = X3 ? so.xl + (size_t)kc * xstep : nullptr;
-        const unsigned short* swl = X3 ? so.wl + (size_t)kc * wstep : nullptr;
+        const unsigned short* swl = (X3 && !F16) ? so.wl + (size_t)kc * wstep : nullptr;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int i = g >> 1, j = g & 1;
@@ -920,9 +922,9 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
             if (g == 2) { nxt.ah[2] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 64 + fr, fc));
                           nxt.ah[3] = *reinterpret_cast<const bf16x8*>(ns + gswz(wr * 128 + 96 + fr, fc)); }
             if constexpr (X3) {
-                if (g == 3) { nxt.bl[0] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + fr, fc));
+                if (g == 3) { if constexpr (!F16) nxt.bl[0] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + fr, fc));
                               nxt.al[0] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + fr, fc)); }
-                if (g == 4) { nxt.bl[1] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
+                if (g == 4) { if constexpr (!F16) nxt.bl[1] = *reinterpret_cast<const bf16x8*>(ns + LO + G2_A_B + gswz(wc * 64 + 32 + fr, fc));
                               nxt.al[1] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 32 + fr, fc)); }
                 if (g == 5) nxt.al[2] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 64 + fr, fc));
                 if (g == 6) nxt.al[3] = *reinterpret_cast<const bf16x8*>(ns + LO + gswz(wr * 128 + 96 + fr, fc));
@@ -935,18 +937,23 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
             if constexpr (X3) {
                 if (g == 4) dma16_sbase(sxl, 2u * xoff0, lst + LO);
                 if (g == 5) dma16_sbase(sxl, 2u * xoff1, lst + LO + 4096);
-                if (g == 6) dma16_sbase(swl, 2u * woff, lst + LO + G2_A_B);
+                if constexpr (!F16) if (g == 6) dma16_sbase(swl, 2u * woff, lst + LO + G2_A_B);
             }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 4)) {
             if (live) {
+                if constexpr (F16) {
+                    if constexpr (X3) acc[i][j] = mfma_f16(cur.al[i], cur.bh[j], acc[i][j]);
+                    acc[i][j] = mfma_f16(cur.ah[i], cur.bh[j], acc[i][j]);
+                } else {
                 if constexpr (X3) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh[j], acc[i][j], 0, 0, 0);
                     // measurement aid (128): two-term product, the low halves of W dropped (W effectively rounded to bf16)
                     if constexpr (!(ABL & 128)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl[j], acc[i][j], 0, 0, 0);
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh[j], acc[i][j], 0, 0, 0);
+                }
             }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -968,6 +975,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
             }
         } else {
             static_assert((ABL & 16) || S == 1, "the un-interleaved step exists for one K-step per barrier only");
+            static_assert(!F16, "the fp16 form exists for the interleaved step only");
             const int nslot = slot + 1 == R ? 0 : slot + 1;
             if (!(ABL & 2)) issue(kt + R, slot);
             if (!(ABL & 1)) load_frags2<X3>(fb, smem + nslot * STAGE_B, wr, wc, fr, fc);
@@ -1019,6 +1027,18 @@ __global__ __launch_bounds__(256) void stage_x_kernel(const LinearArgs a, unsign
     const float* src = a.X + row_of(a.xmap, m) * a.ldx + kb * 16 + c * 8;
     const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (a.f16) {
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (a.in_act == ACT_SILU) v[e] = act_fn(v[e], ACT_SILU);
+            h[e] = f16_sat(v[e]);
+            l[e] = f16_sat(v[e] - (float)h[e]);
+        }
+        *reinterpret_cast<f16x8*>(hi + i * 8) = h;
+        if (lo) *reinterpret_cast<f16x8*>(lo + i * 8) = l;
+        return;
+    }
     bf16x8 h, l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1085,7 +1105,11 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
         const int64_t nx = (int64_t)a.M * (a.K >> 3);
         hipLaunchKernelGGL(stage_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, a, xh, xl);
     }
-    if (a.Wblk) {
+    if (a.f16) {                 // fp16 forms: W rounded to fp16, pre-blocked by the caller; no low halves
+        if (!a.Wblk_h) return hipErrorInvalidValue;
+        so.wh = reinterpret_cast<const unsigned short*>(a.Wblk_h);
+        so.wl = nullptr;
+    } else if (a.Wblk) {
         so.wh = reinterpret_cast<const unsigned short*>(a.Wblk);
         so.wl = reinterpret_cast<const unsigned short*>(a.Wblk_lo);
     } else {
@@ -1129,6 +1153,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
             if (abl == 0 && ks == 2) kern2 = &linear_glds2_kernel<false, 16, 2>;
             if (abl == 0 && ks == 3) kern2 = &linear_glds2_kernel<false, 16, 3>;
         }
+        if (a.f16) kern2 = &linear_glds2_kernel<X3, 16, 1, true>;
         if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern2), (int)smem2) != hipSuccess) return hipErrorInvalidValue;
         const int tiles_m = (a.M + G2_TM - 1) / G2_TM, tiles_n = (a.N + G2_TN - 1) / G2_TN;
         const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
@@ -1138,6 +1163,7 @@ static hipError_t launch_glds(const LinearArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(kern2, dim3(blocks), dim3(256), smem2, stream, a, so, tiles_n, (int)n_tiles, (pw < tiles_n) ? pw : 0);
         return hipGetLastError();
     }
+    if (a.f16) return hipErrorInvalidValue;         // the fp16 form exists in the two-workgroup kernel only
     const int tiles_m = (a.M + GT - 1) / GT, tiles_n = (a.N + GT - 1) / GT;
     const int64_t n_tiles = (int64_t)tiles_m * tiles_n;
     const int blocks = (int)((n_tiles + 7) / 8) * 8;
@@ -1641,6 +1667,8 @@ hipError_t linear_staged_prepare() {
     constexpr int smem_x3 = 3 * 2 * (G2_A_B + G2_B_B), smem_1 = 6 * (G2_A_B + G2_B_B);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_glds2_kernel<true, 16>), smem_x3);
     if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_glds2_kernel<false, 16>), smem_1);
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_glds2_kernel<true, 16, 1, true>), smem_x3);
+    if (e == hipSuccess) e = ensure_dynamic_lds(reinterpret_cast<const void*>(&linear_glds2_kernel<false, 16, 1, true>), smem_1);
     return e;
 }
 
@@ -1655,10 +1683,10 @@ bool linear_planes_ok(int M, int N, int K, int prec) {
            (int64_t)N * K < ((int64_t)1 << 31);
 }
 
-hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream) {
+hipError_t stage_planes(const float* x, int64_t ldx, int M, int K, int in_act, unsigned short* hi, unsigned short* lo, hipStream_t stream, bool f16) {
     if (!x || !hi || M <= 0 || K <= 0 || (K % 16) != 0 || (ldx & 3) != 0) return hipErrorInvalidValue;
     LinearArgs a;
-    a.X = x; a.ldx = ldx; a.M = M; a.K = K; a.in_act = in_act;
+    a.X = x; a.ldx = ldx; a.M = M; a.K = K; a.in_act = in_act; a.f16 = f16;
     const int64_t nx = (int64_t)M * (K >> 3);
     hipLaunchKernelGGL(stage_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, a, hi, lo);
     return hipGetLastError();
@@ -1714,11 +1742,18 @@ hipError_t linear_big(const LinearArgs& a, hipStream_t stream) {
     const size_t stage_need = linear_stage_bytes(a.Xh ? 0 : a.M, a.Wblk ? 0 : a.N, a.K, a.prec);
     const bool stage_fits = stage_need == 0 || (a.xstage && a.xstage_bytes >= stage_need && (reinterpret_cast<uintptr_t>(a.xstage) & 15) == 0);
     if (a.Xh) {                 // operand planes from the producing kernel: there may be no fp32 X at all, so only the staged kernel will do
-        if (!stage_fits || !linear_planes_ok(a.M, a.N, a.K, a.prec) || (a.prec == PREC_BF16X3 && !a.Xl) || a.xmap.per_batch != 0) return hipErrorInvalidValue;
+        if (!stage_fits || !linear_planes_ok(a.M, a.N, a.K, a.prec) || (a.prec == PREC_BF16X3 && !a.Xl && !a.f16) || a.xmap.per_batch != 0) return hipErrorInvalidValue;
+        if (a.f16) {            // fp16 planes: low halves given = the two-term form, otherwise one term
+            if (!a.Wblk_h) return hipErrorInvalidValue;
+            return a.Xl ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);
+        }
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);
     }
+    // (a.f16 with an fp32 X: the kernels below multiply split-bf16 operands as always and a.f16 only selects the format of the output
+    // planes; the staged form re-lays X as fp16 halves and needs Wblk_h like the planes form)
+    const bool f16_ok = !a.f16 || (a.prec == PREC_BF16X3 && a.Wblk_h);
     // force_staged (the allocation-free entry point) overrides the tuning switches: that entry point promises this kernel
-    if ((a.force_staged || (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any))) && stage_fits &&
+    if (f16_ok && (a.force_staged || (!no_glds && force_wm == 0 && ((tiles_sq >= 900 && ((a.N >= 1024 && a.K >= 512) || (a.N >= 2048 && a.K >= 256 && a.prec == PREC_BF16X3))) || glds_any))) && stage_fits &&
         (a.xstage || stage_need == 0) &&
         (int64_t)a.M * a.K < ((int64_t)1 << 31) && (int64_t)a.N * a.K < ((int64_t)1 << 31))
         return a.prec == PREC_BF16X3 ? launch_glds<true>(a, stream) : launch_glds<false>(a, stream);

@@ -347,18 +347,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs 
         if (rs) { const float4 r = rs[c]; o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w; }
         if (a.y) y[c] = make_float4(o[0], o[1], o[2], o[3]);
         if (a.ph) {             // K-blocked planes [d/16][rows][16]: this lane's 4 values are columns 4c .. 4c+3
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
             const int64_t off = ((int64_t)(c >> 2) * a.rows + row) * 16 + ((4 * c) & 15);
-            bf16x4_t hi;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hi[e] = (__bf16)o[e];
-            *reinterpret_cast<bf16x4_t*>(a.ph + off) = hi;
-            if (a.pl) {
-                bf16x4_t lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(o[e] - (float)hi[e]);
-                *reinterpret_cast<bf16x4_t*>(a.pl + off) = lo;
-            }
+            const Halves4 hv = split_halves4(o, a.pf16);
+            *reinterpret_cast<uint2*>(a.ph + off) = hv.hi;
+            if (a.pl) *reinterpret_cast<uint2*>(a.pl + off) = hv.lo;
         }
     }
 }
@@ -437,7 +429,6 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const LayerNormAr
     const float4* gt = a.gate ? reinterpret_cast<const float4*>(a.gate + mrow * a.ldg) : nullptr;
     const float4* rs = a.res ? reinterpret_cast<const float4*>(a.res + (int64_t)row * a.ldr) : nullptr;
     float4* y = a.y ? reinterpret_cast<float4*>(a.y + (int64_t)row * a.ldy) : nullptr;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int c = ql + 16 * i;                  // float4 index in the row: columns 4c .. 4c+3, block c >> 2
@@ -450,16 +441,9 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const LayerNormAr
         if (!live) continue;
         if (y) y[c] = make_float4(o[0], o[1], o[2], o[3]);
         const int64_t off = ((int64_t)(c >> 2) * a.rows + row) * 16 + ((4 * c) & 15);
-        bf16x4_t hi;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hi[e] = (__bf16)o[e];
-        *reinterpret_cast<bf16x4_t*>(a.ph + off) = hi;
-        if (a.pl) {
-            bf16x4_t lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(o[e] - (float)hi[e]);
-            *reinterpret_cast<bf16x4_t*>(a.pl + off) = lo;
-        }
+        const Halves4 hv = split_halves4(o, a.pf16);
+        *reinterpret_cast<uint2*>(a.ph + off) = hv.hi;
+        if (a.pl) *reinterpret_cast<uint2*>(a.pl + off) = hv.lo;
     }
 }
 
@@ -1332,6 +1316,18 @@ __global__ void to_bf16_kernel(const float* x, uint16_t* y, uint16_t* ylo, int64
 hipError_t to_bf16(const float* x, uint16_t* y, uint16_t* ylo, int64_t n, hipStream_t stream) {
     if (n <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, ylo, n);
+    return hipGetLastError();
+}
+
+__global__ void to_f16_kernel(const float* x, uint16_t* y, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = __builtin_bit_cast(uint16_t, f16_sat(x[i]));
+}
+
+hipError_t to_f16(const float* x, uint16_t* y, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(to_f16_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
     return hipGetLastError();
 }
 

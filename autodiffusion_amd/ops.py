@@ -26,9 +26,19 @@ def to_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def to_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> fp16 bit patterns (int16 tensor), saturating at +-65504."""
+    x = f32c(x)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.int16)
+    check(_lib.load().adx_op_to_f16(ptr(x), ptr(y), x.numel(), current_stream()), "to_f16")
+    return y
+
+
 def prepare_weight(w: torch.Tensor, precision: str = "fp32") -> torch.Tensor:
     """The device form of an (N, K) weight that ``adx_op_linear`` reads under ``precision``."""
     prec = _lib.PRECISIONS[precision]
+    if prec in (_lib.PREC_F16X2, _lib.PREC_F16):        # operand-plane products only: the weight rounded once to fp16
+        return to_f16(w)
     if prec == _lib.PREC_BF16:
         return to_bf16(w)
     if prec == _lib.PREC_BF16X3:

@@ -222,7 +222,7 @@ def bench_dit(args, dev):
     x = torch.randn(M, K, device=dev)
     w32 = torch.randn(N, K, device=dev) * 0.02
     bias = torch.zeros(N, device=dev)
-    mult = 3 if args.precision == "bf16x3" else 1
+    mult = {"bf16x3": 3, "f16x2": 2}.get(args.precision, 1)         # matrix instructions per product
     planes = args.precision != "fp32" and K >= 512 and K % 64 == 0 and ((M + 255) // 256) * ((N + 127) // 128) >= 320
     w = ops.prepare_weight(w32, args.precision)
     if planes:
@@ -240,7 +240,7 @@ def bench_dit(args, dev):
     line = {
         "metric": "denoised trajectories/sec (8s, 80-pt)", "value": round(B / dt, 2), "unit": "trajectories/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "fp32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "fp32", "f16x2": "fp16", "f16": "fp16"}.get(args.precision, "bf16"), "data": "synthetic",
         "config": {"workload": f"{backbone} decoder d={d} L={L} h={h}, {n_steps} DDPM steps (cosine), stochastic sampling, random init, "
                                "synthetic backbone hidden states" + (f", {mc} samples per scenario" if mc > 1 else ""), "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
                    "precision": args.precision, "dense_tflops_whole_pass": round(flops / dt / 1e12, 2)},
@@ -369,22 +369,25 @@ def dit_gemm(dev):
     w32 = torch.randn(N, K, device=dev) * 0.02
     bias = torch.zeros(N, device=dev)
     out = {"shape": {"M": M, "N": N, "K": K}, "peak_tflops": MFMA_BF16_PEAK_TFLOPS}
-    for prec, mult in (("bf16x3", 3), ("bf16", 1)):
+    for prec, mult in (("bf16x3", 3), ("f16x2", 2), ("f16", 1), ("bf16", 1)):      # f16x2 / f16: fp16 operand planes, two / one matrix instructions per product (same peak rate as bf16)
         w = ops.prepare_weight(w32, prec)
-        ws = torch.empty(ops.linear_stage_bytes(M, N, K, prec) + 64, dtype=torch.uint8, device=dev)
         xp, wp = ops.stage_planes(x, prec), ops.block_weight(w, N, K, prec)
         y = torch.empty(M, N, device=dev)
         product = lambda k: [ops.linear_planes(xp, wp, bias, M, N, K, precision=prec, out=y) for _ in range(k)]  # noqa: E731
-        whole = lambda k: [ops.linear(x, w, bias, precision=prec, prepared_n=N, workspace=ws) for _ in range(k)]  # noqa: E731
         product(200)                                         # an idle GPU needs ~150 of these launches (60 ms) before its clocks settle (profiles/gemm_warm_probe.py)
         t = min(time_kernel(product, 20) for _ in range(3))
-        t_whole = min(time_kernel(whole, 20) for _ in range(3))
-        tf, tf_whole = 2.0 * M * N * K / t / 1e12, 2.0 * M * N * K / t_whole / 1e12
+        tf = 2.0 * M * N * K / t / 1e12
         out[prec] = {"us": round(t * 1e6, 1), "tflops": round(tf, 1), "executed_tflops": round(tf * mult, 1),
-                     "frac": round(tf * mult / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "with_relayout": {"us": round(t_whole * 1e6, 1), "executed_tflops": round(tf_whole * mult, 1),
-                                       "frac": round(tf_whole * mult / MFMA_BF16_PEAK_TFLOPS, 4)}}
-        del xp, wp, ws, y
+                     "frac": round(tf * mult / MFMA_BF16_PEAK_TFLOPS, 4)}
+        if prec in ("bf16x3", "bf16"):                       # the one-off caller's form (adx_op_linear_staged) exists for the bf16 modes
+            ws = torch.empty(ops.linear_stage_bytes(M, N, K, prec) + 64, dtype=torch.uint8, device=dev)
+            whole = lambda k: [ops.linear(x, w, bias, precision=prec, prepared_n=N, workspace=ws) for _ in range(k)]  # noqa: E731
+            t_whole = min(time_kernel(whole, 20) for _ in range(3))
+            tf_whole = 2.0 * M * N * K / t_whole / 1e12
+            out[prec]["with_relayout"] = {"us": round(t_whole * 1e6, 1), "executed_tflops": round(tf_whole * mult, 1),
+                                          "frac": round(tf_whole * mult / MFMA_BF16_PEAK_TFLOPS, 4)}
+            del ws
+        del xp, wp, y
     return out
 
 
@@ -474,7 +477,8 @@ def main():
     ap.add_argument("--n-sample", type=int, default=0, help="refiner: sampling steps (default 50; equal to --n-train = DDPM loop)")
     ap.add_argument("--mc-num", type=int, default=1, help="DiT workloads: samples per scenario (--batch counts trajectories)")
     ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32", "f16x2", "f16"],
+                    help="f16x2 / f16 (DiT workloads): fp16 operand planes, two / one matrix instructions per product")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the knee and dit_gemm measurements (profiling runs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise launch, sharding and gather with gloo on the CPU")

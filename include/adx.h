@@ -33,7 +33,15 @@ enum { ADX_ACT_NONE = 0, ADX_ACT_RELU = 1, ADX_ACT_GELU_ERF = 2, ADX_ACT_GELU_TA
        ADX_ACT_TANH = 6 /* stand-alone operator adx_op_act only (action / key-point embeddings of the raster encoder) */ };
 /* GEMM operand type; accumulation is always f32.  BF16X3 (engines only): bf16 MFMA on operands split into
  * high + low bf16 halves (x_lo w_hi + x_hi w_lo + x_hi w_hi), ~16 mantissa bits per operand. */
-enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1, ADX_PREC_BF16X3 = 2 };
+enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1, ADX_PREC_BF16X3 = 2,
+       /* DiT engine and the operand-plane product only: operand planes hold fp16 halves -- activations split into high + low
+        * fp16 halves, weights rounded once to fp16 (2^-12 relative) -- and a product is x_hi w + x_lo w, two matrix instructions
+        * instead of three; every other kernel of such an engine runs as ADX_PREC_BF16X3.  Values beyond the fp16 range
+        * saturate at +-65504. */
+       ADX_PREC_F16X2 = 3,
+       /* the same with the activations rounded once to fp16 as well: one plane per operand, one matrix instruction per product,
+        * 2^-12 relative per operand.  Every other kernel of such an engine still runs as ADX_PREC_BF16X3. */
+       ADX_PREC_F16 = 4 };
 enum { ADX_VARIANT_A = 0, ADX_VARIANT_DIT = 1, ADX_VARIANT_MMDIT = 2 };
 
 /* sampling flags */
@@ -76,7 +84,10 @@ size_t adx_linear_stage_bytes(int M, int N, int K, int prec);
  * 16-byte aligned: the high halves, followed under ADX_PREC_BF16X3 by the low halves.  adx_op_stage_planes writes the
  * planes of fp32 x[M][K]; adx_op_block_weight those of a weight in adx_op_linear's `w` form; adx_op_linear_planes multiplies
  * two plane sets (M >= 256, N >= 64 and a multiple of 4, K >= 512 and a multiple of 64, at least 320 tiles of 256 x 128;
- * anything else is ADX_EINVAL).  Results equal adx_op_linear_staged's bit for bit. */
+ * anything else is ADX_EINVAL).  Results equal adx_op_linear_staged's bit for bit.
+ * Under ADX_PREC_F16X2 the planes hold fp16: x as high + low halves (two planes), the weight -- passed to adx_op_block_weight as
+ * N*K fp16 bit patterns, see adx_op_to_f16 -- as ONE plane, and the product takes two matrix instructions per tile step
+ * (x_hi w + x_lo w); the error is that of rounding w to fp16, 2^-12 relative per weight. */
 size_t adx_linear_planes_bytes(int rows, int K, int prec);
 int adx_op_stage_planes(const float* x, int M, int K, int prec, void* planes, void* stream);
 int adx_op_block_weight(const void* w, int N, int K, int prec, void* blocked, void* stream);
@@ -97,6 +108,7 @@ int adx_op_linear_noalloc(const float* x, const void* w, const float* bias, floa
 int adx_noalloc_init(void);
 size_t adx_noalloc_scratch_bytes(void);
 int adx_op_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+int adx_op_to_f16(const float* x, uint16_t* y, int64_t n, void* stream);     /* fp16 bit patterns, saturating at +-65504 */
 
 /* select_k_from_mc (models/utils.py:120-132 -> utils/modify_traj_utils.py: farthest_point_sample_PointCloud :8-30,
  * run_EM_algorithm / _compute_EM_algorithm :124-219): reduce the M sampled trajectories traj[B][M][L][D] of every

@@ -7,6 +7,9 @@ in every run.  Final-trajectory ADE of each engine precision against the fp32 en
     bf16x3   x_hi w_hi + x_lo w_hi + x_hi w_lo      (three MFMAs per product)
     bf16x2   x_hi w_hi + x_lo w_hi                  (weights rounded to bf16 once, activations split: two MFMAs)
     bf16     x_hi w_hi                              (one MFMA)
+    f16x2    x_hi w + x_lo w on fp16 halves         (weights rounded to fp16 once -- 11 significant bits against bf16's 8 --,
+                                                     activations split: two MFMAs)
+    f16      x w, both rounded once to fp16         (one MFMA; every kernel other than the operand-plane products stays split-bf16)
 
 usage: dit_precision.py [L=24] [scenarios=16] [mc=16] [steps=200] [backbone=DiT]
 """
@@ -65,7 +68,7 @@ ref, dt = run("fp32")
 xy = ref[..., :2]
 print(f"{BB} d={D} L={L} h={H}, {SC} scenarios x {MC} samples, {N} DDPM steps; fp32 engine {dt:.1f} s; |x,y| mean {float(xy.abs().mean()):.1f} m, "
       f"max {float(xy.abs().max()):.1f} m, on the clamp: {float((ref[..., 0].abs() >= 2474.9).float().mean()) * 100:.2f} %", flush=True)
-cases = [(p, p, None) for p in ("bf16x3", "bf16x2", "bf16") if p in _lib.PRECISIONS]
+cases = [(p, p, None) for p in ("bf16x3", "f16x2", "f16", "bf16x2", "bf16") if p in _lib.PRECISIONS]
 if "bf16x2" not in _lib.PRECISIONS and os.environ.get("ADX_TWO_TERM_ABLATION"):
     cases.insert(1, ("x3-w_lo", "bf16x3", "144"))
 for name, prec, abl in cases:

@@ -83,3 +83,13 @@ if [ $part = all ] || [ $part = elementwise ]; then
     pmc pmc_elementwise "TCC_EA0_WRREQ_sum WRITE_SIZE" "layernorm sched_step q_sample normalize add_kernel binary4 randn" python3 profiles/elementwise_bw.py
     cat $O/pmc_elementwise.txt
 fi
+if [ $part = all ] || [ $part = f16 ]; then
+    # fp16 operand-plane precisions of the DiT engine: accuracy at the batch whose products all run on planes, product timings, whole passes
+    ADX_TWO_TERM_ABLATION=1 timeout -k 10 600 python3 -u profiles/dit_precision.py 24 16 16 200 2>&1 | grep -v amdgpu.ids > $O/dit_precision_b256.txt; cat $O/dit_precision_b256.txt
+    timeout -k 10 300 python3 -u profiles/gemm_f16x2.py 2>&1 | grep -v amdgpu.ids > $O/gemm_f16.txt; cat $O/gemm_f16.txt
+    for p in f16 f16x2 bf16x3; do
+        timeout -k 10 400 python3 bench.py --workload dit1024 --precision $p --mc-num 16 --dit-steps 20 --steps 2 --warmup 1 > $O/bench_dit1024_mc16_$p.json 2>> $O/bench.err && cut -c1-120 $O/bench_dit1024_mc16_$p.json
+    done
+    timeout -k 10 400 python3 bench.py --workload dit1024 --precision f16 --dit-steps 20 --steps 2 --warmup 1 > $O/bench_dit1024_f16.json 2>> $O/bench.err
+    trace dit1024_f16 python3 bench.py --workload dit1024 --precision f16 --mc-num 16 --dit-steps 10 --steps 1 --warmup 1
+fi

@@ -138,6 +138,43 @@ def test_op_linear_planes(dev, M, N, K, prec):
         ops.linear_planes(xp[8:], wp, b, M - 1, N, K, precision=prec)    # planes not 16-byte aligned
 
 
+@pytest.mark.parametrize("prec", ["f16x2", "f16"])
+@pytest.mark.parametrize("M,N,K", [(10000, 4100, 512), (20480, 1024, 1024)])
+def test_op_linear_planes_fp16(dev, M, N, K, prec):
+    """ADX_PREC_F16X2: planes of fp16 halves, weights rounded once to fp16, two matrix instructions per product.  Against fp64 on
+    the fp16-rounded weights the kernel is exact to fp32 accumulation (it computes x_hi w + x_lo w, nothing else); against the
+    unrounded weights the error is the weight rounding, 2^-12 relative at most per weight; values beyond the fp16 range
+    saturate instead of becoming infinite.  ADX_PREC_F16: the activations are rounded once as well (one plane, one instruction)."""
+    from autodiffusion_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    xp = ops.stage_planes(x, prec)
+    wp = ops.block_weight(ops.prepare_weight(w, prec), N, K, prec)
+    assert xp.numel() == (4 if prec == "f16x2" else 2) * M * K and wp.numel() >= 2 * N * K
+    y = ops.linear_planes(xp, wp, b, M, N, K, _lib.ACT_GELU_TANH, prec)
+    assert torch.equal(y, ops.linear_planes(xp, wp, b, M, N, K, _lib.ACT_GELU_TANH, prec))
+    act = lambda t: torch.nn.functional.gelu(t, approximate="tanh")  # noqa: E731
+    xr = x[:512].double() if prec == "f16x2" else x[:512].half().double()
+    exact = act(xr @ w.half().double().T + b.double())
+    full = act(x[:512].double() @ w.double().T + b.double())
+    e_exact, e_full = rel_err(y[:512].cpu(), exact.cpu()), rel_err(y[:512].cpu(), full.cpu())
+    print(f"{prec} product M={M} N={N} K={K}: {e_exact:.1e} against fp16-rounded operands, {e_full:.1e} against the operands themselves")
+    assert e_exact < 3e-6 and e_full < 4e-4
+    # the same weights through the split-bf16 product for comparison: the two forms agree to the fp16 rounding of the weights
+    y3 = ops.linear_planes(ops.stage_planes(x, "bf16x3"), ops.block_weight(ops.prepare_weight(w, "bf16x3"), N, K, "bf16x3"), b, M, N, K,
+                           _lib.ACT_GELU_TANH, "bf16x3")
+    assert rel_err(y[:512].cpu(), y3[:512].cpu()) < 4e-4
+    # saturation: 1e6 becomes 65504 in the high half (and the low half saturates too), never infinity
+    big = x.clone()
+    big[0, 0] = 1e6
+    yb = ops.linear_planes(ops.stage_planes(big, prec), wp, b, M, N, K, precision=prec)
+    assert bool(torch.isfinite(yb).all())
+    with pytest.raises(_lib.AdxError):
+        ops.linear(x, w, b, _lib.ACT_NONE, prec)                             # the precision exists for operand planes only
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("M,N,K", [(262144 + 77, 776, 256), (131072, 70, 128), (140000, 96, 64)])
 def test_op_linear_row_stationary(dev, M, N, K, prec):
@@ -1129,6 +1166,54 @@ def test_config_c5_staged_kernels_ade(dev, golden, c5_weights):
     print(f"C5 L=24 bf16x3 B=256: ADE vs fp32 engine, mean {float(a.mean()):.2e} m, worst {float(a.max()):.2e} m")
     assert float(a.max()) < 1e-2
     torch.cuda.empty_cache()
+    # the fp16 engines (operand-plane products on fp16 halves: two matrix instructions per product with split activations, one
+    # with activations rounded once; everything else as split-bf16): same gate, re-run bit-identical
+    for prec in ("f16x2", "f16"):
+        dec = _c5_decoder(c5_weights, prec, dev, MC)
+        half = dec.model(state, batch_size=SC, determin=False, mc_num=MC, noise=noise).clone()
+        assert torch.equal(half, dec.model(state, batch_size=SC, determin=False, mc_num=MC, noise=noise))
+        a = metrics.ade_fde(half[:4].reshape(64, 80, 4).cpu(), ref.reshape(64, 80, 4).cpu())["ade8"]
+        print(f"C5 L=24 {prec} B=256: ADE vs fp32 engine, mean {float(a.mean()):.2e} m, worst {float(a.max()):.2e} m")
+        assert float(a.max()) < 1e-2 and not torch.equal(half, full)
+        del dec
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("prec", ["f16x2", "f16"])
+def test_dit_fp16_plane_engines(dev, prec):
+    """The fp16 precisions of the DiT engine at the smallest width whose products run on operand planes (hidden 512, 2 blocks,
+    128 scenarios): one denoiser call against the fp32 engine (the error is the fp16 rounding of the weights, 2^-12 relative,
+    through 2 blocks), a 4-step stochastic loop finite and repeatable; at a batch too small for any operand-plane product the
+    engine IS the split-bf16 engine, bit for bit; the MM-DiT engine and the refiner refuse the precision."""
+    from autodiffusion_amd import _lib, dit, refiner, synth
+    B, N = 128, 4
+    out = {}
+    for p in ("fp32", "bf16x3", prec):
+        dec = dit.DiffusionDecoder(dit.dit_config(512, 2, 8, "DiT", diffusion_timesteps=N, precision=p))
+        synth.fill_module_(dec, WSEED)
+        dec = dec.to(dev).eval()
+        x = synth.noise(B, (), (80, 4), NSEED).to(dev)
+        t = torch.full((B,), 2, device=dev, dtype=torch.long)
+        state = synth.hidden_state(B, 512, ISEED).to(dev)
+        eps = dec.model.model(x, t, state).clone()
+        small = dec.model.model(x[:4].contiguous(), t[:4].contiguous(), state[:4].contiguous()).clone()
+        noise = synth.noise(B, (N + 1,), (80, 4), NSEED + 1).to(dev)
+        traj = dec.model(state, batch_size=B, determin=False, noise=noise).clone()
+        assert torch.equal(traj, dec.model(state, batch_size=B, determin=False, noise=noise))
+        out[p] = (eps, small, traj)
+        del dec
+        torch.cuda.empty_cache()
+    e3, eh = rel_err(out["bf16x3"][0].cpu(), out["fp32"][0].cpu()), rel_err(out[prec][0].cpu(), out["fp32"][0].cpu())
+    print(f"DiT d=512 denoiser call against the fp32 engine: bf16x3 {e3:.1e}, {prec} {eh:.1e}")
+    assert e3 < 2e-5 and 2e-5 < eh < 2e-3
+    assert torch.equal(out[prec][1], out["bf16x3"][1])              # 320 token rows: no operand-plane product, the same kernels run
+    assert bool(torch.isfinite(out[prec][2]).all())
+    with pytest.raises(_lib.AdxError):
+        mm = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "MM-DiT", diffusion_timesteps=N, precision=prec)).to(dev).eval()
+        mm.model.model(torch.zeros(2, 80, 4, device=dev), torch.zeros(2, device=dev, dtype=torch.long), torch.zeros(2, 80, 64, device=dev))
+    with pytest.raises(_lib.AdxError):
+        da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=10, diffusion_timesteps=10, precision=prec)).to(dev).eval()
+        da.generate(trajectory_prior=synth.trajectory_prior(2, ISEED).to(dev), maps_info=synth.maps_info(2, ISEED).to(dev))
 
 
 @pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
