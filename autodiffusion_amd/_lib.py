@@ -34,6 +34,7 @@ EXPORTS = [
     "adx_op_layernorm_bwd", "adx_op_attention_bwd", "adx_op_attention_stats", "adx_op_weighted_mse_bwd",
     "adx_op_raster_patches", "adx_generate_transition", "adx_op_traj_loss",
     "adx_op_dropout", "adx_op_attention_stats_dropout", "adx_op_attention_bwd_dropout", "adx_op_attention_dropout_mask",
+    "adx_op_rmsnorm", "adx_op_rotary", "adx_moe_workspace_bytes", "adx_op_moe_block",
 ]
 
 
@@ -132,6 +133,10 @@ def load() -> C.CDLL:
         "adx_op_attention_stats_dropout": ([p, p, p, p, p, i, i, i, i, i, f, i, f, C.c_uint64, i, p, p], i),
         "adx_op_attention_bwd_dropout": ([p, p, p, p, p, i, i, i, i, i, f, i, p, p, p, p, i, f, C.c_uint64, i, p, p], i),
         "adx_op_attention_dropout_mask": ([p, i, i, i, i, f, C.c_uint64, i, p], i),
+        "adx_op_rmsnorm": ([p, p, f, i64, i, p, p], i),
+        "adx_op_rotary": ([p, p, p, i, i, i, i, i, i, p], i),
+        "adx_moe_workspace_bytes": ([i64, i, i, i, i], C.c_size_t),
+        "adx_op_moe_block": ([p, p, p, p, p, i64, i, i, i, i, i, p, C.c_size_t, p, p], i),
     }
     for name, (args, res) in protos.items():
         fn = getattr(lib, name)

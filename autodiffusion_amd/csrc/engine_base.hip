@@ -412,6 +412,13 @@ ADX_API int adx_op_linear_planes(const void* x_planes, const void* w_blocked, co
     if (prec == ADX_PREC_BF16X3) { a.Xl = xh + (size_t)M * K; a.Wblk_lo = wh + (size_t)N * K; a.Wlo = a.Wblk_lo; }
     if (f16) { a.f16 = true; a.Wblk_h = wh; a.Wblk_lo = nullptr; a.Wlo = wh; }     // one fp16 plane of W (X: two planes or one)
     a.ldx = K; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act; a.prec = prec;
+#ifdef ADX_MEASURE          // measurement library only: the epilogue with other outputs (results are not the documented ones)
+    if (const char* o = getenv("ADX_PLANES_OUT")) {     // read per call
+        if (o[0] == 'n') a.Y = nullptr;                                                     // "none": the epilogue computes and stores nothing
+        if (o[0] == 'p') { a.Y = nullptr; a.Yh = reinterpret_cast<unsigned short*>(y);      // "planes": high halves (+ "planes2": low halves)
+                           if (o[6] == '2') a.Yl = a.Yh + (size_t)M * N; }                  //            of the result as the next product's operand
+    }
+#endif
     return done(linear(a, (hipStream_t)stream), "linear_planes");
 }
 

@@ -256,6 +256,10 @@ struct EngineDiT final : adx_engine {
             const bool pk_d = planes && linear_planes_ok(R, 3 * d, d, prec) && linear_planes_ok(R, 4 * d, d, prec);
             const bool pk_4d = planes && linear_planes_ok(R, d, 4 * d, prec);
             const bool pk_sil = planes && linear_planes_ok(Rc, 6 * d, d, prec);
+            // fp16 engines also take the out-projection through planes (one re-layout pass over the attention output, then the
+            // one- or two-instruction product); with split-bf16 operands the tiled kernel on fp32 input measured no slower
+            const char* po_env = getenv("ADX_DIT_OUT_PLANES");       // measurement switch, read per call: 0 = tiled kernel
+            const bool pk_o = planes && f16x2 && linear_planes_ok(R, d, d, prec) && !(po_env && po_env[0] == '0');
             const bool x3 = prec == ADX_PREC_BF16X3 && !f16_single;      // the planes carry low halves
             auto use_planes = [&](LinearArgs& a, const unsigned short* ph, int K) { a.Xh = ph; a.Xl = x3 ? ph + (size_t)R * K : nullptr; };
             auto out_planes = [&](LinearArgs& a, unsigned short* ph, int N) { a.Y = nullptr; a.Yh = ph; a.Yl = x3 ? ph + (size_t)R * N : nullptr; };
@@ -279,6 +283,10 @@ struct EngineDiT final : adx_engine {
                 ADX_HIP(attention(at, s));
                 LinearArgs o = lin(ATT, d, p + ".attn.self_attn.out_proj.weight", 0, d, d, p + ".attn.self_attn.out_proj.bias", Z0, d, R);
                 o.res = HN; o.ldr = d;
+                if (pk_o) {             // Z1P is free here: norm1 writes it after this product, linear1 reads it after that
+                    ADX_HIP(stage_planes(ATT, d, R, d, ACT_NONE, Z1P, x3 ? Z1P + (size_t)R * d : nullptr, s, true));
+                    use_planes(o, Z1P, d);
+                }
                 ADX_HIP(linear(o, s));
                 ADX_TRY(ln_affine(Z0, Z1, p + ".attn.norm1", R, nullptr, 0, nullptr, s, pk_d ? Z1P : nullptr));
                 LinearArgs f1 = lin(Z1, d, p + ".attn.linear1.weight", 0, 4 * d, d, p + ".attn.linear1.bias", FF, 4 * d, R, ACT_RELU);

@@ -32,22 +32,29 @@ __device__ __forceinline__ float xor32_max(float x) {
 __device__ __forceinline__ _Float16 f16_sat(float v) { return (_Float16)__builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }
 
 // Four consecutive values as 16-bit operand halves of a matrix product (8 bytes each): hi = the value rounded to bf16 (or, with
-// f16, to fp16), lo = (value - hi) rounded the same way.
+// f16, to fp16, saturating), lo = (value - hi) rounded the same way.  Scalars in, packed words out: an array parameter here made
+// the callers keep their value arrays in scratch memory.
 struct Halves4 { uint2 hi, lo; };
-__device__ __forceinline__ Halves4 split_halves4(const float (&v)[4], bool f16) {
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 p = {f16_sat(a), f16_sat(b)};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ Halves4 split_halves4(float v0, float v1, float v2, float v3, bool f16) {
     Halves4 r;
     if (f16) {
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        h4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[e] = f16_sat(v[e]); lo[e] = f16_sat(v[e] - (float)hi[e]); }
-        r.hi = __builtin_bit_cast(uint2, hi); r.lo = __builtin_bit_cast(uint2, lo);
+        const _Float16 h0 = f16_sat(v0), h1 = f16_sat(v1), h2 = f16_sat(v2), h3 = f16_sat(v3);
+        r.hi = make_uint2(pack_f16x2(v0, v1), pack_f16x2(v2, v3));
+        r.lo = make_uint2(pack_f16x2(v0 - (float)h0, v1 - (float)h1), pack_f16x2(v2 - (float)h2, v3 - (float)h3));
     } else {
-        typedef __bf16 b4 __attribute__((ext_vector_type(4)));
-        b4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
-        r.hi = __builtin_bit_cast(uint2, hi); r.lo = __builtin_bit_cast(uint2, lo);
+        const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1, h2 = (__bf16)v2, h3 = (__bf16)v3;
+        r.hi = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        r.lo = make_uint2(pack_bf16x2(v0 - (float)h0, v1 - (float)h1), pack_bf16x2(v2 - (float)h2, v3 - (float)h3));
     }
     return r;
 }

@@ -60,6 +60,7 @@ __device__ __forceinline__ int64_t row_of(const RowMap& r, int m) {
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_B + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 // Registers that carry the next K-step from global memory to LDS, and the per-thread addresses they are filled from.
 // X: 4 rows per thread (xr + 16 WM i), floats xk..xk+3.  W: rows br + 64 i (2 per thread with 256 threads, 1 with 512).
@@ -151,7 +152,11 @@ __device__ __forceinline__ void act_patch(float (&v)[RP][4], int act) {
 // EXTRA = false is the instance for calls without position table, gate and residual: it contains no vector-memory load at
 // all, so no wait at all (where the optional loads sit under branches the compiler emits one unconditional wait for
 // everything in flight after them -- the previous patch's stores included -- whether or not a load was issued).
-template <int RP, bool EXTRA>
+// F16OUT: element type of the output planes -- 0 bf16, 1 fp16, -1 whatever a.f16 says at run time.  Callers whose loop over
+// patches is large (eight patches per wave) pass a constant, chosen once outside that loop: both conversion paths in one loop
+// body took the body past the size at which the compiler still unrolls it, and the accumulators, then indexed by the loop
+// counter, went to scratch memory.
+template <int RP, bool EXTRA, int F16OUT = -1>
 __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* ep, int m_base, int n, int nc, int lane, float4 bvec) {
     const int c4 = (lane & 7) * 4;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -197,9 +202,29 @@ __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* 
             for (int i = 0; i < RP; ++i) {
                 if (pm[i] < 0) continue;
                 const int64_t o = ((int64_t)(n >> 4) * a.M + pm[i]) * 16 + (n & 15);
-                const Halves4 hv = split_halves4(v[i], a.f16);
-                *reinterpret_cast<uint2*>(a.Yh + o) = hv.hi;
-                if (a.Yl) *reinterpret_cast<uint2*>(a.Yl + o) = hv.lo;
+                if (F16OUT < 0 ? a.f16 : F16OUT == 1) {
+                    f16x4 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hi[e] = f16_sat(v[i][e]);
+                    *reinterpret_cast<f16x4*>(a.Yh + o) = hi;
+                    if (a.Yl) {
+                        f16x4 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = f16_sat(v[i][e] - (float)hi[e]);
+                        *reinterpret_cast<f16x4*>(a.Yl + o) = lo;
+                    }
+                } else {
+                    bf16x4 hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hi[e] = (__bf16)v[i][e];
+                    *reinterpret_cast<bf16x4*>(a.Yh + o) = hi;
+                    if (a.Yl) {
+                        bf16x4 lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lo[e] = (__bf16)(v[i][e] - (float)hi[e]);
+                        *reinterpret_cast<bf16x4*>(a.Yl + o) = lo;
+                    }
+                }
             }
         }
     }
@@ -211,7 +236,7 @@ __device__ __forceinline__ void epilogue_rows(const LinearArgs& a, const float* 
 // With RP = 4 nothing in a patch waits for a store of the same patch; RP = 1 needs the fewest registers.
 // EXTRA: the call has a position table, gate or residual (the caller tests that once, outside its loop over patches, so that
 // each loop body holds one instance of this code and still unrolls: the accumulators are indexed by the loop counter).
-template <int RP, bool EXTRA>
+template <int RP, bool EXTRA, int F16OUT = -1>
 __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float* ep, int m_base, int n_base, int lane, bool vec,
                                                const float* lds_bias = nullptr, const float4* bias_reg = nullptr) {
     const int c4 = (lane & 7) * 4, n = n_base + c4;
@@ -223,7 +248,7 @@ __device__ __forceinline__ void epilogue_patch(const LinearArgs& a, const float*
         if (bias_reg) bvec = *bias_reg;
         else if (lds_bias) bvec = *reinterpret_cast<const float4*>(lds_bias + n);
         else if (a.bias) bvec = *reinterpret_cast<const float4*>(a.bias + n);
-        epilogue_rows<RP, EXTRA>(a, ep, m_base, n, nc, lane, bvec);
+        epilogue_rows<RP, EXTRA, F16OUT>(a, ep, m_base, n, nc, lane, bvec);
         return;
     }
 #pragma unroll 1
@@ -401,16 +426,19 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void linear_big_kernel(c
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
-    auto patches = [&](auto extra) {
+    auto patches = [&](auto extra, auto f16out) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int i = t >> 1, j = t & 1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
-            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+            epilogue_patch<4, decltype(extra)::value, decltype(f16out)::value>(a, ep, m0 + wr * 64 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
         }
     };
-    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
+    typedef std::integral_constant<int, 0> out_bf16;
+    typedef std::integral_constant<int, 1> out_f16;
+    if (a.f16 && a.Yh) { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_f16{}); else patches(std::false_type{}, out_f16{}); }
+    else { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_bf16{}); else patches(std::false_type{}, out_bf16{}); }
 }
 
 // ============================================================================================================
@@ -550,16 +578,19 @@ __global__ __launch_bounds__(512, 1) void linear_ws_kernel(const LinearArgs a, i
                      (!a.res || ((a.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
-    auto patches = [&](auto extra) {
+    auto patches = [&](auto extra, auto f16out) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int i = t >> 1, j = t & 1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][r];
-            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+            epilogue_patch<4, decltype(extra)::value, decltype(f16out)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
         }
     };
-    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
+    typedef std::integral_constant<int, 0> out_bf16;
+    typedef std::integral_constant<int, 1> out_f16;
+    if (a.f16 && a.Yh) { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_f16{}); else patches(std::false_type{}, out_f16{}); }
+    else { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_bf16{}); else patches(std::false_type{}, out_bf16{}); }
 }
 
 template <bool X3, bool SILU>
@@ -768,16 +799,19 @@ __global__ __launch_bounds__(512, 1) void linear_glds_kernel(const LinearArgs a,
     }
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
-    auto patches = [&](auto extra) {
+    auto patches = [&](auto extra, auto f16out) {
 #pragma unroll
         for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
             const int i = t >> 1, j = t & 1;
 #pragma unroll
             for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
-            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+            epilogue_patch<4, decltype(extra)::value, decltype(f16out)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
         }
     };
-    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
+    typedef std::integral_constant<int, 0> out_bf16;
+    typedef std::integral_constant<int, 1> out_f16;
+    if (a.f16 && a.Yh) { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_f16{}); else patches(std::false_type{}, out_f16{}); }
+    else { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_bf16{}); else patches(std::false_type{}, out_bf16{}); }
 }
 
 // ============================================================================================================
@@ -1004,16 +1038,19 @@ __global__ __launch_bounds__(256, 2) void linear_glds2_kernel(const LinearArgs a
     }
     float4 bv[2];
     load_patch_bias(a, n0 + wc * 64, lane, vec, bv);
-    auto patches = [&](auto extra) {
+    auto patches = [&](auto extra, auto f16out) {
 #pragma unroll
         for (int t = 0; t < ((ABL & 8) ? 0 : 8); ++t) {
             const int i = t >> 1, j = t & 1;
 #pragma unroll
             for (int q = 0; q < 16; ++q) ep[((q & 3) + 8 * (q >> 2) + 4 * fc) * EP_LD + fr] = acc[i][j][q];
-            epilogue_patch<4, decltype(extra)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
+            epilogue_patch<4, decltype(extra)::value, decltype(f16out)::value>(a, ep, m0 + wr * 128 + i * 32, n0 + wc * 64 + j * 32, lane, vec, nullptr, &bv[j]);
         }
     };
-    if (a.pos || a.gate || a.res) patches(std::true_type{}); else patches(std::false_type{});
+    typedef std::integral_constant<int, 0> out_bf16;
+    typedef std::integral_constant<int, 1> out_f16;
+    if (a.f16 && a.Yh) { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_f16{}); else patches(std::false_type{}, out_f16{}); }
+    else { if (a.pos || a.gate || a.res) patches(std::true_type{}, out_bf16{}); else patches(std::false_type{}, out_bf16{}); }
 }
 
 // X (fp32, row map, optional SiLU) -> K-blocked bf16 planes [K/16][M][16]: high halves and, when lo != nullptr,

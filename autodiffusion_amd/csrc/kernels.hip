@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const LayerNormArgs 
         if (a.y) y[c] = make_float4(o[0], o[1], o[2], o[3]);
         if (a.ph) {             // K-blocked planes [d/16][rows][16]: this lane's 4 values are columns 4c .. 4c+3
             const int64_t off = ((int64_t)(c >> 2) * a.rows + row) * 16 + ((4 * c) & 15);
-            const Halves4 hv = split_halves4(o, a.pf16);
+            const Halves4 hv = split_halves4(o[0], o[1], o[2], o[3], a.pf16);
             *reinterpret_cast<uint2*>(a.ph + off) = hv.hi;
             if (a.pl) *reinterpret_cast<uint2*>(a.pl + off) = hv.lo;
         }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const LayerNormAr
         if (!live) continue;
         if (y) y[c] = make_float4(o[0], o[1], o[2], o[3]);
         const int64_t off = ((int64_t)(c >> 2) * a.rows + row) * 16 + ((4 * c) & 15);
-        const Halves4 hv = split_halves4(o, a.pf16);
+        const Halves4 hv = split_halves4(o[0], o[1], o[2], o[3], a.pf16);
         *reinterpret_cast<uint2*>(a.ph + off) = hv.hi;
         if (a.pl) *reinterpret_cast<uint2*>(a.pl + off) = hv.lo;
     }
@@ -1104,7 +1104,11 @@ hipError_t attention(const AttentionArgs& a, hipStream_t stream) {
     static const bool no_mfma = [] { const char* e = getenv("ADX_ATTN_VALU"); return e && e[0] == '1'; }();   // tuning knob
     if (!no_mfma && attention_mfma_ok(a)) return attention_mfma(a, stream);
     const size_t smem = sizeof(float) * ((size_t)QT * a.Skv + QT * DC + KC * (DC + 1));
-    if (smem > 64 * 1024) return hipErrorInvalidValue;   // Skv <= ~880 for the general kernel
+    if (smem > 160 * 1024) return hipErrorInvalidValue;  // Skv <= ~2200 for the general kernel (the score rows of 16 queries live in LDS)
+    if (smem > 64 * 1024) {                              // beyond the default limit: the causal passes of the mixture-of-experts decoder (788 .. 873 keys)
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return attr;
+    }
     dim3 grid((a.Sq + QT - 1) / QT, a.H, a.B);
     hipLaunchKernelGGL(attn_general_kernel, grid, dim3(256), smem, stream, a);
     return hipGetLastError();

@@ -259,6 +259,31 @@ int adx_op_traj_loss(const float* logits, const float* label, int B, int T, int 
 int adx_op_raster_patches(const float* raster, int B, int H, int W, int C, int framenum, int traffic, float* out, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Conditioning producer, middle stage: the sparse mixture-of-experts decoder that STR.embedding_to_hidden runs
+ * (models/backbone/str_base.py:379-387 on the MixtralModel of models/backbone/mixtral.py:17-19; the decoder layer itself is
+ * third-party `transformers`, pinned 4.42.3 in the reference's requirements.txt:212).  Its products and its causal attention are
+ * adx_op_linear and adx_op_attention (mask_off = number of cached positions); these are the operators it needs beyond them.
+ * ------------------------------------------------------------------------------------------ */
+/* y[r] = weight * (x[r] * rsqrt(mean(x[r]^2) + eps)) over rows of d floats (MixtralRMSNorm). */
+int adx_op_rmsnorm(const float* x, const float* weight, float eps, int64_t rows, int d, float* y, void* stream);
+/* Rotate-half rotary embedding, in place: x[B][S][H * dh], token s of every item at position pos0 + s;
+ * (x1, x2) -> (x1 cos - x2 sin, x2 cos + x1 sin) with x1 / x2 the two halves of a head and cos / sin tables [n_pos][dh / 2]
+ * (angle(p, j) = p * rope_theta^(-2 j / dh)). */
+int adx_op_rotary(float* x, const float* cos_table, const float* sin_table, int B, int S, int H, int dh, int pos0, int n_pos, void* stream);
+/* The expert block: y[t] = res[t] + sum_j w_j E_{e_j}(x[t]),  E_e(x) = W2_e (silu(W1_e x) * W3_e x),  (e_j, w_j) = the top_k largest
+ * of softmax(router_w x[t]) renormalised to sum one (ties: lowest expert index).  x, res (nullable), y: [T][d] fp32; router_w [E][d] fp32;
+ * w13 [E][2 * inter][d] (rows 0 .. inter-1 of an expert = W1, the gate; the rest = W3) and w2 [E][d][inter] in the form
+ * adx_op_linear reads under `precision` (fp32 values; bf16 bits; under ADX_PREC_BF16X3 the high halves of all experts followed by
+ * the low halves).  The router always computes in fp32.  No host synchronisation, no atomics: tokens are bucketed per expert on
+ * the device, both products run over the 64-row-padded buckets, results are combined in slot order.  workspace: at least
+ * adx_moe_workspace_bytes(T, d, inter, E, top_k) bytes, 16-byte aligned; after the call its first T * top_k int32 hold the chosen
+ * experts and, from the next multiple of 256 bytes on, T * top_k floats hold their weights.  d and inter multiples of 32, E <= 64,
+ * top_k <= 8. */
+size_t adx_moe_workspace_bytes(int64_t T, int d, int inter, int E, int top_k);
+int adx_op_moe_block(const float* x, const float* res, const float* router_w, const void* w13, const void* w2, int64_t T, int d, int inter,
+                     int E, int top_k, int precision, void* workspace, size_t workspace_bytes, float* y, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Operators of the training paths (fp32): the refiner, the flattened wrapper and the decoder twin.  The reference differentiates
  * its losses with torch autograd (loss.backward() on TrajRefiner.py:417-452 over transformer.py:189-273; diffusion_decoder.py:346-365
  * over libs/diffusionTransformer.py:24-199); the entry points below are the backward of the forward operators above, plus the few

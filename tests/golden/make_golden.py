@@ -797,9 +797,79 @@ def g20_trajectory_decoder():
     save("g20_trajectory_decoder", **out)
 
 
+# ----------------------------------------------------------------------------- G21: the backbone between encoder and head, and STR.generate
+def mixtral_checkpoint_tensors(name: str, p: torch.Tensor):
+    """A parameter of the installed transformers' MixtralModel -> [(name in a transformers-4.42.3 checkpoint, view of p)]: the fused
+    expert tensors of newer releases are the per-expert w1 | w3 (gate, up) and w2 (down) matrices of the pinned one."""
+    name = name.replace(".mlp.gate.", ".block_sparse_moe.gate.")
+    if name.endswith(".mlp.experts.gate_up_proj"):
+        base, inter = name[:-len("mlp.experts.gate_up_proj")] + "block_sparse_moe.experts.", p.shape[1] // 2
+        return [(f"{base}{e}.{w}.weight", p[e, lo:lo + inter]) for e in range(p.shape[0]) for w, lo in (("w1", 0), ("w3", inter))]
+    if name.endswith(".mlp.experts.down_proj"):
+        base = name[:-len("mlp.experts.down_proj")] + "block_sparse_moe.experts."
+        return [(f"{base}{e}.w2.weight", p[e]) for e in range(p.shape[0])]
+    return [(name, p)]
+
+
+def g21_str_generate():
+    """STR_Mixtral.generate of the reference (models/backbone/str_base.py:457-813, mixtral.py): ViT raster encoder -> sparse
+    mixture-of-experts decoder run once per key point on the growing prefix -> trajectory head.  nuplan task, no proposals, k = 1,
+    key points 'specified_backward' through the separate embedding, MLP key-point and trajectory heads.  Two sizes: 'small' (n_embd
+    64, 2 layers, 4 query / 2 key-value heads, 8 experts of width 256, top 2; B = 2) and the reference's 'mixtral-small' (n_embd 256,
+    4 layers, 8 heads, 8 experts of width 1024, top 2; B = 1).  Weights seeded under their reference-checkpoint names.  Stored: the
+    outputs, the final pass's hidden states (every row from 780 on, every 16th before), and per layer of the final pass the router
+    margin (smallest gap between the second and third largest probability: a fixture with near-ties would not pin anything)."""
+    from transformer4planning.utils.args import ModelArguments
+    from transformer4planning.models.backbone.mixtral import STR_Mixtral, STRMixtralConfig
+    out = {}
+    for tag, n_embd, n_layer, n_head, n_kv, inter, vit_inter, B in (("small", 64, 2, 4, 2, 256, 96, 2), ("full", 256, 4, 8, 8, 1024, 3072, 1)):
+        ma = ModelArguments()
+        ma.model_name, ma.raster_encoder_type, ma.vit_intermediate_size = "scratch-mixtral-small", "vit", vit_inter
+        cfg = STRMixtralConfig()
+        cfg.update_by_model_args(ma)
+        cfg.n_layer = cfg.num_hidden_layers = n_layer
+        cfg.n_embd = cfg.d_model = cfg.hidden_size = n_embd
+        cfg.n_inner = cfg.intermediate_size = inter
+        cfg.n_head = cfg.num_attention_heads = n_head
+        cfg.num_key_value_heads = n_kv
+        model = STR_Mixtral(cfg).float().eval()
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                n = ("encoder.image_downsample." + vit_checkpoint_name(n[len("encoder.image_downsample."):])) if n.startswith("encoder.image_downsample.") else n
+                for ck, view in mixtral_checkpoint_tensors(n, p):
+                    view.copy_(synth.seeded_param(ck, tuple(view.shape), WSEED))
+        margins = []
+
+        def hook(mod, args, res):
+            prob = torch.softmax(res[0].float(), dim=-1).sort(dim=-1, descending=True).values
+            margins.append(float((prob[:, cfg.num_experts_per_tok - 1] - prob[:, cfg.num_experts_per_tok]).min()))
+        hooks = [l.mlp.gate.register_forward_hook(hook) for l in model.transformer.layers]
+        hidden = []
+        hooks.append(model.transformer.register_forward_hook(lambda mod, args, res: hidden.append(res["last_hidden_state"])))
+        high, low = synth.occupancy_raster(B, 58, ISEED + 2), synth.occupancy_raster(B, 58, ISEED + 3)
+        actions = synth.noise(B, (), (4, 4), NSEED + 9) * torch.tensor([2.0, 0.3, 0.0, 0.1])
+        label = synth.trajectory_prior(B, ISEED)
+        with torch.no_grad():
+            res = model.generate(high_res_raster=high, low_res_raster=low, context_actions=actions, trajectory_label=label)
+        for h in hooks:
+            h.remove()
+        last = hidden[-1]
+        assert len(hidden) == 6 and last.shape == (B, 788 + 5 + 80, n_embd), (len(hidden), last.shape)
+        out[f"{tag}_context_actions"] = actions
+        out[f"{tag}_traj_logits"], out[f"{tag}_key_points_logits"] = res["traj_logits"], res["key_points_logits"]
+        out[f"{tag}_maps_info_every7"] = res["maps_info"][:, ::7]
+        out[f"{tag}_hidden_tail"], out[f"{tag}_hidden_every16"] = last[:, 780:], last[:, :780:16]
+        out[f"{tag}_router_margin"] = np.array(margins[-n_layer:], dtype=np.float32)
+        out[f"{tag}_config"] = np.array([n_embd, n_layer, n_head, n_kv, inter, cfg.num_local_experts, cfg.num_experts_per_tok, vit_inter, B])
+        out[f"{tag}_rms_eps_rope_theta"] = np.array([cfg.rms_norm_eps, cfg.rope_parameters["rope_theta"]], dtype=np.float64)
+        print(f"g21 {tag}: traj rms {float(res['traj_logits'].pow(2).mean().sqrt()):.3f}, key points {res['key_points_logits'][0].tolist()}, "
+              f"hidden rms {float(last.pow(2).mean().sqrt()):.3f}, router margins {margins[-n_layer:]}")
+    save("g21_str_generate", **out)
+
+
 ALL = {"g1": g1_schedules, "g2": g2_g3_misc, "g4": g4_variant_a, "g5": g5_dit, "g6": g6_g7_loops, "g8": g8_chunk_loop, "g9": g9_dit_loop,
        "g10": g10_metrics, "g11": g11_select_modes, "g12": g12_configs, "g13": g13_forward_loss, "g14": g14_refiner_grads, "g15": g15_twin_grads, "g16": g16_mmdit_grads, "g17": g17_c5_loop, "g18": g18_raster_encoder, "g19": g19_dropout_grads,
-       "g20": g20_trajectory_decoder}
+       "g20": g20_trajectory_decoder, "g21": g21_str_generate}
 
 if __name__ == "__main__":
     torch.manual_seed(0)

@@ -601,3 +601,76 @@ def test_trajectory_decoder(golden, kind):
     # headings a whole turn apart are the same heading
     a = torch.tensor([0.3, -2.0, 3.0])
     assert float(td.mean_circular_error(a + 2 * np.pi, a)) < 1e-10 and abs(float(td.mean_circular_error(a, a + 4.0)) - (2 * np.pi - 4.0) ** 2) < 1e-4
+
+
+def str_model_from_recording(g, tag, precision="fp32"):
+    """The STR_Mixtral of one G21 case with the recording's seeded weights (parameter names are the reference checkpoint's), its
+    decoder configuration for the oracle, and the recording's inputs."""
+    from autodiffusion_amd import str_backbone
+    n_embd, n_layer, n_head, n_kv, inter, n_exp, top_k, vit_inter, B = [int(v) for v in g[tag + "_config"]]
+    eps, theta = [float(v) for v in g[tag + "_rms_eps_rope_theta"]]
+    cfg = str_backbone.str_config("mixtral-small", n_embd=n_embd, n_layer=n_layer, n_head=n_head, n_inner=inter, num_key_value_heads=n_kv,
+                                  num_local_experts=n_exp, num_experts_per_tok=top_k, vit_intermediate_size=vit_inter, rms_norm_eps=eps,
+                                  rope_theta=theta, precision=precision)
+    model = synth.fill_module_(str_backbone.STR_Mixtral(cfg), WSEED).eval()
+    ocfg = dict(n_layer=n_layer, n_head=n_head, n_kv_head=n_kv, n_experts=n_exp, top_k=top_k, rms_eps=eps, rope_theta=theta)
+    batch = dict(high_res_raster=synth.occupancy_raster(B, 58, ISEED + 2), low_res_raster=synth.occupancy_raster(B, 58, ISEED + 3),
+                 context_actions=T(g[tag + "_context_actions"]), trajectory_label=synth.trajectory_prior(B, ISEED))
+    return model, ocfg, batch
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_str_generate(golden, tag):
+    """The oracle's STR.generate (raster encoder -> mixture-of-experts decoder once per key point -> trajectory head) against the
+    recording of the reference's STR_Mixtral.generate: trajectory prior, key points, map tokens and the final pass's hidden states.
+    The recording's router margins (gap between the second and third largest probability) are far above fp32 rounding, so the
+    expert choices are pinned too."""
+    from oracle import str_backbone as osb
+    g = golden("g21_str_generate")
+    model, ocfg, batch = str_model_from_recording(g, tag)
+    assert float(g[tag + "_router_margin"].min()) > 5e-6
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    out = osb.str_generate(sd, ocfg, batch["high_res_raster"], batch["low_res_raster"], batch["context_actions"], batch["trajectory_label"],
+                           [79, 39, 19, 9, 4])
+    assert rel_err(out["traj_logits"], g[tag + "_traj_logits"]) < 1e-5
+    assert rel_err(out["key_points_logits"], g[tag + "_key_points_logits"]) < 2e-5
+    assert rel_err(out["maps_info"][:, ::7], g[tag + "_maps_info_every7"]) < 1e-5
+    assert rel_err(out["last_hidden_state"][:, 780:], g[tag + "_hidden_tail"]) < 2e-5
+    assert rel_err(out["last_hidden_state"][:, :780:16], g[tag + "_hidden_every16"]) < 2e-5
+
+
+def test_mixtral_oracle_pieces():
+    """Known answers of the decoder's parts: RMSNorm of a constant row, the rotary embedding as a plane rotation that leaves
+    position 0 alone and preserves norms, an expert block whose router is forced onto one expert, and causality (a later token does
+    not change an earlier hidden state)."""
+    from oracle import str_backbone as osb
+    x = torch.full((2, 8), 3.0)
+    assert torch.allclose(osb.rms_norm(x, torch.ones(8) * 2, 0.0), torch.full((2, 8), 2.0))
+    cos, sin = osb.rotary_tables(5, 8, 10000.0)
+    q = torch.randn(1, 2, 5, 8, generator=torch.Generator().manual_seed(0))
+    r = osb.rotate(q, cos, sin)
+    assert torch.equal(r[:, :, 0], q[:, :, 0]) and torch.allclose(r.norm(dim=-1), q.norm(dim=-1), atol=1e-5)
+    np.testing.assert_allclose(float(r[0, 0, 1, 0]), float(q[0, 0, 1, 0] * np.cos(1.0) - q[0, 0, 1, 4] * np.sin(1.0)), rtol=1e-5)
+    d, inter, E = 8, 16, 4
+    gsd = synth.seeded_state([("gate.weight", (E, d))] + [(f"experts.{e}.{w}.weight", (inter, d) if w != "w2" else (d, inter))
+                                                           for e in range(E) for w in ("w1", "w2", "w3")], WSEED)
+    gsd["gate.weight"] = torch.zeros(E, d)
+    gsd["gate.weight"][2] = 50.0                               # all-positive input: expert 2 wins, a tie among the others
+    xin = torch.rand(3, d, generator=torch.Generator().manual_seed(1)) + 0.1
+    got = osb.moe_block(gsd, "", xin, E, 1)
+    want = torch.nn.functional.linear(torch.nn.functional.silu(xin @ gsd["experts.2.w1.weight"].T) * (xin @ gsd["experts.2.w3.weight"].T),
+                                      gsd["experts.2.w2.weight"])
+    assert torch.allclose(got, want, atol=1e-6)
+    g = torch.Generator().manual_seed(2)
+    shapes = [("transformer.norm.weight", (16,))]
+    for w, s in (("self_attn.q_proj", (16, 16)), ("self_attn.k_proj", (8, 16)), ("self_attn.v_proj", (8, 16)), ("self_attn.o_proj", (16, 16)),
+                 ("block_sparse_moe.gate", (4, 16)), ("input_layernorm", (16,)), ("post_attention_layernorm", (16,))):
+        shapes.append((f"transformer.layers.0.{w}.weight", s))
+    for e in range(4):
+        shapes += [(f"transformer.layers.0.block_sparse_moe.experts.{e}.w1.weight", (32, 16)), (f"transformer.layers.0.block_sparse_moe.experts.{e}.w3.weight", (32, 16)),
+                   (f"transformer.layers.0.block_sparse_moe.experts.{e}.w2.weight", (16, 32))]
+    sd = synth.seeded_state(shapes, WSEED)
+    cfg = dict(n_layer=1, n_head=4, n_kv_head=2, n_experts=4, top_k=2, rms_eps=1e-5, rope_theta=1e4)
+    emb = torch.randn(2, 6, 16, generator=g)
+    full = osb.mixtral_forward(sd, emb, cfg)
+    assert torch.allclose(osb.mixtral_forward(sd, emb[:, :4], cfg), full[:, :4], atol=1e-6)
