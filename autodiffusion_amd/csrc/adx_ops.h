@@ -113,6 +113,8 @@ struct AttentionArgs {
 hipError_t attention(const AttentionArgs& a, hipStream_t stream);         // picks attention_mfma when attention_mfma_ok(a)
 bool attention_mfma_ok(const AttentionArgs& a);                            // Skv <= 128, head dims multiples of 16, no mask
 hipError_t attention_mfma(const AttentionArgs& a, hipStream_t stream);    // attn_mfma.hip
+bool attention_long_ok(const AttentionArgs& a);                            // any length, optional mask, equal head dims that are multiples of 16 up to 128
+hipError_t attention_long(const AttentionArgs& a, hipStream_t stream);    // attn_mfma.hip: keys in chunks of 64, online softmax
 
 // Attention of a FEW queries (Sq <= 16 per launch group) against many keys, head_dim 4: one workgroup per
 // (batch item, group of NQ queries), all heads; keys are spread over the threads and the per-thread softmax

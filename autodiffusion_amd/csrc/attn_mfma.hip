@@ -137,6 +137,119 @@ __global__ __launch_bounds__(64) void attn_mfma_kernel(const AttentionArgs a) {
 }
 
 // ============================================================================================================
+// Long or masked sequences (the causal passes of the mixture-of-experts decoder: 788 .. 873 keys, and its one-token passes over
+// the cached keys): the kernel above with the keys walked in chunks of 64 and an online softmax.  One wavefront per
+// (batch item, head, 16 queries); per chunk: four score tiles (fp32 16x16x4 MFMAs), mask, running maximum m and the factor
+// alpha = 2^(m_old - m_new) that rescales the running sum and the output accumulators (both indexed by query the way the score
+// accumulator is: query = 4 (lane >> 4) + register), probabilities through a 16 x 64 LDS patch back into A-fragment order,
+// O += P V.  Chunks whose first key no query of the tile may see are never visited, so a causal pass costs half the square and
+// a one-token pass over n cached keys n / 64 chunks of one wavefront.  Key 0 must be visible to every query (mask_off >= 0 or
+// no mask): a row of the first chunk is then never empty and m stays finite.
+// ============================================================================================================
+constexpr int LC = 64;                // keys per chunk
+constexpr int LP_LD = LC + 4;         // floats per row of the probability patch
+
+template <int DT>                     // head width / 16 (score contraction steps and output tiles)
+__global__ __launch_bounds__(64) void attn_long_kernel(const AttentionArgs a) {
+    __shared__ __attribute__((aligned(16))) float Ps[16 * LP_LD];
+    const int lane = threadIdx.x, r16 = lane & 15, k4 = lane >> 4;
+    const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int Skv = a.Skv;
+    const float* Qb = a.Q + (int64_t)b * a.q_batch_stride + (int64_t)h * a.dh;
+    const float* Kb = a.K + (int64_t)b * a.k_batch_stride + (int64_t)h * a.dh;
+    const float* Vb = a.V + (int64_t)b * a.v_batch_stride + (int64_t)h * a.dv;
+    const float* qrow = Qb + (int64_t)min(q0 + r16, a.Sq - 1) * a.ldq + 4 * k4;
+    float4 qv[DT];
+#pragma unroll
+    for (int c = 0; c < DT; ++c) qv[c] = *reinterpret_cast<const float4*>(qrow + 16 * c);
+    const float f = a.scale * LOG2E_A;
+    // keys the tile may see: all of them, or up to the last query's limit
+    const int last_q = min(q0 + 15, a.Sq - 1);
+    const int n_keys = a.mask_off < 0 ? Skv : min(Skv, last_q + a.mask_off + 1);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};       // l: this lane's part of the row sum
+    f32x4 o[DT];
+#pragma unroll
+    for (int u = 0; u < DT; ++u) o[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int k0 = 0; k0 < n_keys; k0 += LC) {
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float* krow = Kb + (int64_t)min(k0 + 16 * t + r16, Skv - 1) * a.ldk + 4 * k4;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                const float4 kv = *reinterpret_cast<const float4*>(krow + 16 * c);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[c].x, kv.x, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[c].y, kv.y, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[c].z, kv.z, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[c].w, kv.w, s[t], 0, 0, 0);
+            }
+        }
+        float mx[4] = {m[0], m[1], m[2], m[3]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int key = k0 + 16 * t + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + 4 * k4 + r;
+                const bool ok = key < Skv && (a.mask_off < 0 || key <= q + a.mask_off);
+                s[t][r] = ok ? s[t][r] * f : -INFINITY;
+                mx[r] = fmaxf(mx[r], s[t][r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], d, 64));
+            const float alpha = exp2_fast(m[r] - mx[r]);            // 0 on the first chunk (m = -inf, mx finite)
+            m[r] = mx[r];
+            l[r] *= alpha;
+#pragma unroll
+            for (int u = 0; u < DT; ++u) o[u][r] *= alpha;
+        }
+        __syncthreads();                                             // the previous chunk's patch has been read
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2_fast(s[t][r] - m[r]);
+                l[r] += p;
+                Ps[(4 * k4 + r) * LP_LD + 16 * t + r16] = p;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < LC / 16; ++g) {                          // 16 keys per step: this lane's 4 keys are 16 g + 4 k4 + j
+            const float4 pv = *reinterpret_cast<const float4*>(&Ps[r16 * LP_LD + 16 * g + 4 * k4]);
+            const float pj[4] = {pv.x, pv.y, pv.z, pv.w};
+            float vv[4][DT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* vrow = Vb + (int64_t)min(k0 + 16 * g + 4 * k4 + j, Skv - 1) * a.ldv + r16;        // masked keys carry p = 0
+#pragma unroll
+                for (int u = 0; u < DT; ++u) vv[j][u] = vrow[16 * u];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < DT; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(pj[j], vv[j][u], o[u], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) l[r] += __shfl_xor(l[r], d, 64);
+        l[r] = rcp_fast(l[r]);
+        const int q = q0 + 4 * k4 + r;
+        if (q < a.Sq) {
+#pragma unroll
+            for (int u = 0; u < DT; ++u) a.O[(int64_t)b * a.o_batch_stride + (int64_t)q * a.ldo + (int64_t)h * a.dv + 16 * u + r16] = o[u][r] * l[r];
+        }
+    }
+}
+
+// ============================================================================================================
 // The same computation with ONE workgroup per (batch item, head): wave w owns queries 16 w .. 16 w + 15 and all waves share
 // K and V through LDS, so every K / V element is read from memory once (the kernel above reads them once per query tile)
 // and with 16-byte loads.  For head dimensions that are multiples of 32 and Sq == Skv <= 128.
@@ -525,6 +638,28 @@ hipError_t attention_mfma(const AttentionArgs& a, hipStream_t stream) {
     dim3 grid((a.Sq + 15) / 16, a.H, a.B);
     if (a.dv >= 64) hipLaunchKernelGGL(attn_mfma_kernel<4>, grid, dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(attn_mfma_kernel<2>, grid, dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+bool attention_long_ok(const AttentionArgs& a) {
+    return !a.state && !a.key0 && a.dh == a.dv && a.dh >= 16 && (a.dh % 16) == 0 && a.dh <= 128 && (a.ldq % 4) == 0 && (a.ldk % 4) == 0 &&
+           (a.q_batch_stride % 4) == 0 && (a.k_batch_stride % 4) == 0 && (reinterpret_cast<uintptr_t>(a.Q) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.K) & 15) == 0;
+}
+
+hipError_t attention_long(const AttentionArgs& a, hipStream_t stream) {
+    if (!attention_long_ok(a)) return hipErrorInvalidValue;
+    dim3 grid((a.Sq + 15) / 16, a.H, a.B);
+    switch (a.dh / 16) {
+        case 1: hipLaunchKernelGGL(attn_long_kernel<1>, grid, dim3(64), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(attn_long_kernel<2>, grid, dim3(64), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(attn_long_kernel<3>, grid, dim3(64), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(attn_long_kernel<4>, grid, dim3(64), 0, stream, a); break;
+        case 5: hipLaunchKernelGGL(attn_long_kernel<5>, grid, dim3(64), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(attn_long_kernel<6>, grid, dim3(64), 0, stream, a); break;
+        case 7: hipLaunchKernelGGL(attn_long_kernel<7>, grid, dim3(64), 0, stream, a); break;
+        default: hipLaunchKernelGGL(attn_long_kernel<8>, grid, dim3(64), 0, stream, a); break;
+    }
     return hipGetLastError();
 }
 

@@ -1103,6 +1103,9 @@ hipError_t attention(const AttentionArgs& a, hipStream_t stream) {
     }
     static const bool no_mfma = [] { const char* e = getenv("ADX_ATTN_VALU"); return e && e[0] == '1'; }();   // tuning knob
     if (!no_mfma && attention_mfma_ok(a)) return attention_mfma(a, stream);
+    // long or masked sequences of wide heads (the mixture-of-experts decoder): chunked keys + online softmax on the fp32 matrix cores;
+    // head width 16 keeps the thread-per-query kernel above, mask_off >= 0 guarantees that every query sees key 0
+    if (!no_mfma && attention_long_ok(a)) return attention_long(a, stream);
     const size_t smem = sizeof(float) * ((size_t)QT * a.Skv + QT * DC + KC * (DC + 1));
     if (smem > 160 * 1024) return hipErrorInvalidValue;  // Skv <= ~2200 for the general kernel (the score rows of 16 queries live in LDS)
     if (smem > 64 * 1024) {                              // beyond the default limit: the causal passes of the mixture-of-experts decoder (788 .. 873 keys)

@@ -288,6 +288,63 @@ def bench_transition(args, dev):
                    "captures": m.transition_model.diffusion.engine().capture_count()}}), flush=True)
 
 
+def bench_str(args, dev):
+    """Phase 1 of generate(): rasters -> trajectory prior + map tokens through STR_Mixtral (ViT raster encoder, the 'mixtral-small'
+    mixture-of-experts decoder with its autoregressive key-point loop, trajectory head), then optionally the refiner on top
+    (--with-refiner).  B = the reference's evaluation batch per device (8) unless --batch is given."""
+    from autodiffusion_amd import refiner, str_backbone, synth
+    B = args.batch or 8
+    prec = args.precision
+    model = synth.fill_module_(str_backbone.STR_Mixtral(str_backbone.str_config("mixtral-small", precision=prec)), 11).to(dev).eval()
+    batch = dict(high_res_raster=synth.occupancy_raster(B, 58, 7).to(dev), low_res_raster=synth.occupancy_raster(B, 58, 8).to(dev),
+                 context_actions=(synth.noise(B, (), (4, 4), 1241) * torch.tensor([2.0, 0.3, 0.0, 0.1])).to(dev),
+                 trajectory_label=synth.trajectory_prior(B, 7).to(dev))
+
+    def timed(fn):
+        for _ in range(max(args.warmup, 1)):
+            out = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps, out
+    dt, out = timed(lambda: model.generate(**batch))
+    assert bool(torch.isfinite(out["traj_logits"]).all())
+    enc_dt, _ = timed(lambda: model.encoder(is_training=False, **batch))
+    line = {
+        "metric": "trajectory priors/sec (phase 1 of generate())", "value": round(B / dt, 2), "unit": "trajectories/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32" if prec == "fp32" else "bf16", "data": "synthetic",
+        "config": {"workload": "STR_Mixtral.generate, mixtral-small (n_embd 256, 4 layers, 8 heads, 8 experts of width 1024, top 2), ViT raster "
+                               "encoder (hidden 128, 12 layers, 2 x 4 x 197 tokens per scenario), 5 autoregressive key points with cached keys, "
+                               "873 tokens per scenario, random init, synthetic rasters", "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
+                   "precision": prec},
+        "stages_ms": {"raster_encoder": round(enc_dt * 1e3, 3), "decoder_and_heads": round((dt - enc_dt) * 1e3, 3)},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import str_backbone as osb
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        ocfg = dict(n_layer=4, n_head=8, n_kv_head=8, n_experts=8, top_k=2, rms_eps=1e-5, rope_theta=1e6)
+        cb = {k: v[:1].cpu() for k, v in batch.items()}
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            osb.str_generate(sd, ocfg, cb["high_res_raster"], cb["low_res_raster"], cb["context_actions"], cb["trajectory_label"], [79, 39, 19, 9, 4])
+            cdt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(1.0 / cdt, 3), "unit": "trajectories/s", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": f"fp32 CPU oracle of the same model on ONE scenario, the reference's six full decoder passes ({cdt:.2f} s)"}
+    if args.with_refiner:
+        da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=10, diffusion_timesteps=100, sampling_timesteps=50, objective="pred_noise",
+                                                                    beta_schedule="cosine", precision="bf16x3"), str_model=model)
+        synth.reference_init_(da.diffusion, 11)
+        da = da.to(dev).eval()
+        rdt, rout = timed(lambda: da.generate(seed=1, **batch))
+        assert bool(torch.isfinite(rout["traj_logits"]).all())
+        line["with_refiner"] = {"ms_per_step": round(rdt * 1e3, 3), "value": round(B / rdt, 2), "unit": "trajectories/s",
+                                "note": "rasters -> refined trajectories: phase 1 + the refiner's chunk loop (frame_stack 10, DDIM 50 of 100), device noise"}
+    print(json.dumps(line), flush=True)
+
+
 def cpu_baseline():
     """BASELINE.json configs[0] on the host cores with the fp32 CPU oracle: B = 16, frame_stack 10, 100-step DDPM (cosine,
     pred_noise).  Bounded sample: ONE of the 8 chunks with all 100 steps on every allowed thread (the 8 chunks are
@@ -470,7 +527,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="scenarios per GPU (default: 1024 for the refiner, the configured batch)")
-    ap.add_argument("--workload", default="refiner", choices=["refiner", "strdiffdit"] + sorted(DIT_WORKLOADS),
+    ap.add_argument("--workload", default="refiner", choices=["refiner", "strdiffdit", "str"] + sorted(DIT_WORKLOADS),
                     help="refiner = the headline configuration; the DiT decoder workloads run on one GPU only")
     ap.add_argument("--frame-stack", type=int, default=0, help="refiner: points per chunk (default 10; 80 = whole trajectory)")
     ap.add_argument("--n-train", type=int, default=0, help="refiner: training timesteps (default 100)")
@@ -479,6 +536,7 @@ def main():
     ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32", "f16x2", "f16"],
                     help="f16x2 / f16 (DiT workloads): fp16 operand planes, two / one matrix instructions per product")
+    ap.add_argument("--with-refiner", action="store_true", help="str workload: also time phase 1 + refiner end to end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the knee and dit_gemm measurements (profiling runs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise launch, sharding and gather with gloo on the CPU")
@@ -512,6 +570,8 @@ def main():
     if args.workload != "refiner":
         if world > 1:
             raise SystemExit("the DiT and latent-carrying workloads are single-GPU measurements")
+        if args.workload == "str":
+            return bench_str(args, dev)
         return bench_transition(args, dev) if args.workload == "strdiffdit" else bench_dit(args, dev)
 
     from autodiffusion_amd import schedules

@@ -171,3 +171,24 @@ def test_rasters_to_refined_trajectories_on_the_device(dev, golden):
     by_hand = da.generate(trajectory_prior=phase1["traj_logits"], maps_info=phase1["maps_info"], noise=noise)
     assert out["traj_logits"].shape == (B, 80, 4) and bool(torch.isfinite(out["traj_logits"]).all())
     assert torch.equal(out["traj_logits"], by_hand["traj_logits"])
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,dh,mask_off", [(2, 8, 788, 788, 32, 0), (3, 4, 1, 793, 32, 792), (2, 2, 81, 873, 64, 792), (1, 3, 200, 200, 48, -1),
+                                                    (2, 2, 37, 300, 128, 263), (1, 2, 130, 130, 32, 1)])
+def test_op_attention_long_sequences(dev, B, H, Sq, Skv, dh, mask_off):
+    """Attention over more than 128 keys and / or under the 'key j visible to query i iff j <= i + mask_off' mask with head widths
+    that are multiples of 16 (keys walked in chunks with an online softmax on the fp32 matrix cores): the decoder's context pass,
+    its one-token passes over cached keys, its final pass, an unmasked case and wide heads, against fp64."""
+    from autodiffusion_amd import ops
+    g = torch.Generator().manual_seed(Sq + Skv + dh)
+    q, k, v = (torch.randn(B, s, H * dh, generator=g) for s in (Sq, Skv, Skv))
+    got = ops.attention(q.to(dev), k.to(dev), v.to(dev), H, mask_off=mask_off).cpu()
+    qd, kd, vd = (t.double().reshape(B, -1, H, dh).transpose(1, 2) for t in (q, k, v))
+    s = qd @ kd.transpose(-1, -2) / dh ** 0.5
+    if mask_off >= 0:
+        vis = torch.arange(Skv)[None, :] <= torch.arange(Sq)[:, None] + mask_off
+        s = s.masked_fill(~vis, float("-inf"))
+    ref = (torch.softmax(s, dim=-1) @ vd).transpose(1, 2).reshape(B, Sq, H * dh)
+    e = rel_err(got, ref)
+    print(f"attention B={B} H={H} Sq={Sq} Skv={Skv} dh={dh} mask_off={mask_off}: rel err {e:.1e}")
+    assert e < 5e-6
