@@ -182,10 +182,10 @@ struct EncRowsArgs {
 };
 size_t enc_rows_image_bytes();
 hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, const float* Wq, void* image,
-                                hipStream_t stream);
+                                hipStream_t stream, int f16_mats = 0);   // f16_mats: bit m = the 16-bit fragments of matrix m (Wo, W1, W2, Wkv, Wq) hold fp16 (the mixed modes of enc_rows)
 size_t enc_rows_packed_bytes(int B, int L);
 hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream);      // once per chunk: x0/q/state -> packed
-hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream);  // once per step
+hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream, int mix = 0);  // once per step; mix (split-bf16 mode, gate table), fp16 products: 1 second FFN product, 2 out-projection, 4 first FFN product
 size_t enc_rows_g_bytes(int B, int L);
 // Gate-table form (once per chunk instead of enc_rows_pack): packed <- x0 and o / l in lane order, gates[step][tile][lane] <- the
 // fold gates of every step (tq: [n_steps][96] per-step q | k | v rows of the time token).  A step then passes
@@ -208,7 +208,7 @@ struct AttnGArgs {
     float scale = 1.f;
 };
 bool attention_g_ok(int n_keep);
-hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream);
+hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream, int mix = 0);     // mix (split-bf16 mode): 1 weighted sums in fp16, 3 scores and V too
 
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
 hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);

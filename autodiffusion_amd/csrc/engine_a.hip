@@ -72,6 +72,8 @@ struct EngineA final : adx_engine {
     float *ATTb = nullptr;                    // second buffer of ATT (XB is the second buffer of XA)
     float *GT = nullptr;                      // [n_steps][tiles][64] float4: the fold gates of every step of the chunk (gate-table form of the row kernel)
     bool gate_table = false;
+    int mix = 0;               // products with both operands rounded once to fp16 (set at finalize): 1 | 16 | 32 the row kernel's second FFN product, out-projection and
+                               // first FFN product, 2 the weighted sums of the last encoder attention, 4 its scores and V (with 2)
     float *Q1C = nullptr;                     // [2][B][T + 1][d] layer-1 queries of the visible rows, by step parity (LayerNorm-row attention)
     hipStream_t side_stream = nullptr, att_stream = nullptr;
     hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_att[2] = {nullptr, nullptr};
@@ -217,9 +219,14 @@ struct EngineA final : adx_engine {
             if (!rows_image) ADX_HIP(hipMalloc(&rows_image, enc_rows_image_bytes()));
             if (!rows_vecs) ADX_HIP(hipMalloc(&rows_vecs, sizeof(float) * 416));
             const std::string p0 = "encoder.layers.0", p1 = "encoder.layers.1";
+            // engines created with ADX_PREC_F16 (cfg.precision reads ADX_PREC_BF16X3): every product of the two per-step kernels that
+            // walk all conditioning rows with both operands rounded once to fp16.  ADX_A_MIX (measurement knob, read here) picks a subset.
+            mix = f16_single ? 55 : 0;
+            if (const char* mx = getenv("ADX_A_MIX")) { if (cfg.precision == ADX_PREC_BF16X3) mix = atoi(mx); }
+            if ((mix & 0x31) && (mix & 0x31) != 0x31) mix &= ~0x31;       // the row kernel has one mixed instance: all three products or none
             ADX_HIP(enc_rows_build_image(P(p0 + ".self_attn.out_proj.weight"), P(p0 + ".linear1.weight"), P(p0 + ".linear2.weight"),
                                          P(p1 + ".self_attn.in_proj_weight") + (int64_t)d * d, P(p1 + ".self_attn.in_proj_weight"),
-                                         rows_image, s));
+                                         rows_image, s, ((mix & 1) ? 4 : 0) | ((mix & 16) ? 1 : 0) | ((mix & 32) ? 2 : 0)));
             struct { const float* src; int off, n; } parts[] = {
                 {P(p0 + ".self_attn.out_proj.bias"), 0, 32}, {P(p0 + ".norm2.weight"), 32, 32}, {P(p0 + ".norm2.bias"), 64, 32},
                 {P(p0 + ".linear2.bias"), 96, 32}, {P(p1 + ".norm1.weight"), 128, 32}, {P(p1 + ".norm1.bias"), 160, 32},
@@ -504,7 +511,7 @@ struct EngineA final : adx_engine {
             g.q1 = Q1C + (int64_t)par * B * (T + 1) * d; g.ldq1 = d; g.q1_item_stride = (int64_t)(T + 1) * d;
             g.O = par ? ATTb : ATT; g.ldo = d; g.o_batch_stride = (int64_t)L * d;
             g.B = B; g.L = L; g.n_keep = T + 1; g.scale = 1.0f / sqrtf((float)(d / H));
-            ADX_HIP(attention_g(g, cfg.precision, s));
+            ADX_HIP(attention_g(g, cfg.precision, s, (mix >> 1) & 3));
         } else {
             ADX_HIP(attention_few_queries(fused_attn_args(B, par), s));
         }
@@ -555,7 +562,7 @@ struct EngineA final : adx_engine {
         if (step >= 0 && fused) {
             // layer 0 and layer 1 up to its attention: three launches
             prof_begin(1, s);
-            ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s));
+            ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s, (mix & 1) | ((mix >> 3) & 6)));
             prof_end(s);
             prof_begin(2, s);
             ADX_TRY(last_attention(B, 0, s));
@@ -672,7 +679,7 @@ struct EngineA final : adx_engine {
         for (int it = 0; it < iters; ++it) {
             if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
             else if (stage == 1) {
-                ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s));
+                ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s, (mix & 1) | ((mix >> 3) & 6)));
             } else if (stage == 2) ADX_TRY(last_attention(B, 0, s));
             else if (stage == 3) {
                 if (!tail_ok && !tail_mfma_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
@@ -758,7 +765,7 @@ struct EngineA final : adx_engine {
                     z = noise + (int64_t)(1 + zi) * n;
                 }
                 if (k >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
-                ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s));
+                ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s, (mix & 1) | ((mix >> 3) & 6)));
                 if (overlap_streams >= 3 && attn_g) {
                     // the row kernel of step k + 1 does not wait for this attention: its outputs (rows, queries, residual rows)
                     // go to the other parity, and the buffers of this parity are free again once the tail of step k is done

@@ -531,8 +531,10 @@ ADX_API int adx_engine_create(const adx_model_config* cfg, adx_engine** out) {
     if (cfg->precision != ADX_PREC_F32 && cfg->precision != ADX_PREC_BF16 && cfg->precision != ADX_PREC_BF16X3 && cfg->precision != ADX_PREC_F16X2 &&
         !f16_single)
         return fail(ADX_EINVAL, "engine_create: unknown precision");
-    if ((cfg->precision == ADX_PREC_F16X2 || f16_single) && cfg->variant != ADX_VARIANT_DIT)
-        return fail(ADX_EINVAL, "engine_create: ADX_PREC_F16X2 / ADX_PREC_F16 are precisions of the DiT engine (its operand-plane products)");
+    if (cfg->precision == ADX_PREC_F16X2 && cfg->variant != ADX_VARIANT_DIT)
+        return fail(ADX_EINVAL, "engine_create: ADX_PREC_F16X2 is a precision of the DiT engine (its operand-plane products)");
+    if (f16_single && cfg->variant == ADX_VARIANT_MMDIT)
+        return fail(ADX_EINVAL, "engine_create: ADX_PREC_F16 is a precision of the DiT engine (its operand-plane products) and of the refiner engine (its per-step kernels)");
     adx_model_config base = *cfg;
     const bool f16x2 = cfg->precision == ADX_PREC_F16X2 || f16_single;
     if (f16x2) base.precision = ADX_PREC_BF16X3;

@@ -24,6 +24,7 @@
 #include "fastmath.h"
 
 #include <math.h>
+#include <algorithm>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -66,7 +67,7 @@ struct ImageSrc {
     const float* W[5];   // Wo [32][32], W1 [128][32], W2 [32][128], Wkv [64][32], Wq [32][32]
 };
 
-__global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short* img_bf) {
+__global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short* img_bf, int f16_mats) {
     const int nt_count[5] = {1, 4, 1, 2, 1};
     const int Kdim[5] = {32, 32, 128, 32, 32};
     int tile = 0;
@@ -81,8 +82,14 @@ __global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short*
                     const int s = e >> 9, l = (e >> 3) & 63, j = e & 7;
                     const int k = 32 * it + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
                     const float w = src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + k];
-                    const unsigned short hi = f2bf_(w);
                     const int idx = ((tile * 2 + s) * 64 + l) * 8 + j;
+                    if ((f16_mats >> mat) & 1) {                // this matrix as fp16 halves (the mixed modes read the high ones)
+                        const _Float16 hh = (_Float16)w, hl = (_Float16)(w - (float)hh);
+                        img_bf[idx] = __builtin_bit_cast(unsigned short, hh);
+                        img_bf[NFRAG_BF * 64 * 8 + idx] = __builtin_bit_cast(unsigned short, hl);
+                        continue;
+                    }
+                    const unsigned short hi = f2bf_(w);
                     img_bf[idx] = hi;
                     img_bf[NFRAG_BF * 64 * 8 + idx] = f2bf_(w - bf2f_(hi));
                 }
@@ -152,6 +159,33 @@ __device__ __forceinline__ f32x16 mm_w(const WFrag& w, const f32x16& in, f32x16 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.al[s], bhv, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.ah[s], bhv, acc, 0, 0, 0);
     }
+    return acc;
+}
+
+// The same product with BOTH operands rounded once to fp16 (one matrix instruction per 16 k, one conversion per pair of values
+// instead of six vector instructions): w.ah holds fp16 bit patterns here (build_image_kernel with w2_f16).  fp16 keeps 11
+// significand bits against bf16's 8; the values it is used on are bounded (GELU outputs, softmax weights <= 1, LayerNorm rows).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+__device__ __forceinline__ f16x8 to_f16x8(const f32x16& in, int s) {
+    f16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (_Float16)in[8 * s + j];
+    return b;
+}
+
+__device__ __forceinline__ f32x16 mm_h(const unsigned char* lds_img, int tile, const f32x16& in, f32x16 acc, int lane) {
+    const unsigned short* whi = reinterpret_cast<const unsigned short*>(lds_img) + (tile * 2 * 64 + lane) * 8;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(whi + s * 64 * 8), to_f16x8(in, s), acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 mm_w_h(const WFrag& w, const f32x16& in, f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w.ah[s]), to_f16x8(in, s), acc, 0, 0, 0);
     return acc;
 }
 
@@ -382,7 +416,9 @@ __device__ __forceinline__ void land_row(RowIn& in) {
 // four stores of 1 KB of contiguous memory per tile) for attention_g instead of projecting and storing K | V.
 // ABL: measurement aid (results are wrong except for 16): 1 the FFN activation is the identity, 2 no FFN products, 4 no stores of
 // the row output, 8 every tile re-reads the wave's first tile (L2 hits instead of HBM), 16 GELU with unpacked FMAs (same bits)
-template <int PREC, int WAVES, bool GOUT, bool GATES, int ABL = 0>
+// MIX (split-bf16 mode only), bits: products with both operands rounded once to fp16 -- 1 the second FFN product, 2 the attention
+// out-projection, 4 the first FFN product (the image must have been built with the same matrices as fp16: bit m <-> matrix m of the image)
+template <int PREC, int WAVES, bool GOUT, bool GATES, int ABL = 0, int MIX = 0>
 __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
     constexpr int NT = WAVES == 4 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -462,7 +498,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             }
         }
         // ---- y1 = x0 + Wo att + bo
-        f32x16 y1 = mm<PREC>(img, tile_base(0), att, zero16(), lane);
+        f32x16 y1 = (MIX & 2) ? mm_h(img, tile_base(0), att, zero16(), lane) : mm<PREC>(img, tile_base(0), att, zero16(), lane);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 x = in.x[g];
@@ -483,7 +519,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
                     const float4 b = *reinterpret_cast<const float4*>(b1 + 32 * nt + 8 * g + 4 * h);
                     f[4 * g + 0] = b.x; f[4 * g + 1] = b.y; f[4 * g + 2] = b.z; f[4 * g + 3] = b.w;
                 }
-                if constexpr ((ABL & 2) != 0) { for (int q = 0; q < 16; ++q) f[q] += hn[q]; } else f = mm_w(w1, hn, f);
+                if constexpr ((ABL & 2) != 0) { for (int q = 0; q < 16; ++q) f[q] += hn[q]; } else if constexpr ((MIX & 4) != 0) f = mm_w_h(w1, hn, f); else f = mm_w(w1, hn, f);
                 const WFrag w2 = load_w(img, tile_base(2) + nt, lane);          // lands under the GELU
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -496,7 +532,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
                 }
                 w1 = load_w(img, tile_base(1) + min(nt + 1, 3), lane);          // lands under the MFMAs below
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr ((ABL & 2) != 0) { for (int q = 0; q < 16; ++q) acc2[q] += f[q]; } else acc2 = mm_w(w2, f, acc2);
+                if constexpr ((ABL & 2) != 0) { for (int q = 0; q < 16; ++q) acc2[q] += f[q]; } else if constexpr ((MIX & 1) != 0) acc2 = mm_w_h(w2, f, acc2); else acc2 = mm_w(w2, f, acc2);
             }
         } else {
 #pragma unroll 1
@@ -652,12 +688,21 @@ constexpr float AG_NEG = -1.0e30f;
 //     O^T += V^T P^T      (lane <-> column, registers <-> feature), P = 2^(S - running max): the online softmax keeps its
 //                          maximum, sum and rescale factor per LANE, because a column lives on a lane in S^T and in O^T alike.
 // Only the four features of a column's own head are meaningful in O^T; they are picked at the end.
-template <int PREC, int ABL = 0>      // ABL: measurement aid (results are wrong except for 16): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights, 16 hand-placed instruction order
+// MIX (split-bf16 mode only), bits: 1 the weighted sums O^T += V^T P^T with V and P rounded once to fp16; 2 also the scores and V
+// from g, the folded queries and Wv rounded once to fp16
+template <int PREC, int ABL = 0, int MIX = 0>      // ABL: measurement aid (results are wrong except for 16): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights, 16 hand-placed instruction order
 __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
     __shared__ float mrg[(6 + 48) * 64];
     __shared__ Opnd<PREC> qsh[3][64];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h2 = lane >> 5;
     const Opnd<PREC> wv = weight_opnd<PREC>(img_f32, img_bf, tile_base(3) + 1, lane);
+    f16x8 wvh[2] = {};                                      // Wv rounded once to fp16 (MIX & 2)
+    if constexpr ((MIX & 2) != 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wvh[s][j] = (_Float16)((float)wv.h[s][j] + (float)wv.l[s][j]);
+    }
     const float qs = a.scale * LOG2E_F;
     const int64_t r0 = (int64_t)b * a.L, r1 = r0 + a.L;
     // The query operand is the same for both wavefronts and every group: built once, kept in LDS (48 registers otherwise).
@@ -678,7 +723,13 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
                 for (int g = 0; g < 4; ++g)
                     if (g == (hd >> 1)) { f[4 * g] = q.x * qs; f[4 * g + 1] = q.y * qs; f[4 * g + 2] = q.z * qs; f[4 * g + 3] = q.w * qs; }
             }
-            qsh[nb][lane] = to_opnd<PREC>(mma<PREC>(wkt, to_opnd<PREC>(f), zero16()));
+            const f32x16 qt = mma<PREC>(wkt, to_opnd<PREC>(f), zero16());
+            if constexpr ((MIX & 2) != 0) {
+                Opnd<PREC> qh;                                  // fp16 bit patterns in the high-half slots
+                qh.h[0] = __builtin_bit_cast(bf16x8, to_f16x8(qt, 0)); qh.h[1] = __builtin_bit_cast(bf16x8, to_f16x8(qt, 1));
+                qh.l[0] = qh.h[0]; qh.l[1] = qh.h[1];
+                qsh[nb][lane] = qh;
+            } else qsh[nb][lane] = to_opnd<PREC>(qt);
         }
     }
     __syncthreads();
@@ -727,10 +778,37 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
                 l[nb] = fmaf(l[nb], fac, sum);
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) o[nb][reg] *= fac;
-                if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
+                if constexpr (MIX != 0) return sc;
+                else if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
                 else return to_opnd<PREC>(sc);
             };
-            if constexpr (ABL == 0 && PREC == PREC_BF16X3) {          // (the measurement variants remove parts of the hand-placed form below)
+            if constexpr (MIX != 0) {                                  // one fp16 instruction per weighted sum and 16 keys
+                f32x16 acc4[4] = {zero16(), zero16(), zero16(), zero16()};
+                if constexpr ((MIX & 2) != 0) {                        // scores and V from fp16 operands as well
+                    const f16x8 gh[2] = {to_f16x8(g16, 0), to_f16x8(g16, 1)};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb)
+                            acc4[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], __builtin_bit_cast(f16x8, qsh[nb][lane].h[s]), acc4[nb], 0, 0, 0);
+                        acc4[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh[s], wvh[s], acc4[3], 0, 0, 0);
+                    }
+                } else {
+                    const Opnd<PREC> q0 = qsh[0][lane], q1 = qsh[1][lane], q2 = qsh[2][lane];
+                    const Opnd<PREC>* const A4[4] = {&gop, &gop, &gop, &gop};
+                    const Opnd<PREC>* const B4[4] = {&q0, &q1, &q2, &wv};
+                    mma_x3_interleaved<4>(A4, B4, acc4);
+                }
+                const f16x8 v0 = to_f16x8(acc4[3], 0), v1 = to_f16x8(acc4[3], 1);
+                const f32x16 p0 = soft(0, acc4[0]), p1 = soft(1, acc4[1]), p2 = soft(2, acc4[2]);
+                const f16x8 pa[3][2] = {{to_f16x8(p0, 0), to_f16x8(p0, 1)}, {to_f16x8(p1, 0), to_f16x8(p1, 1)}, {to_f16x8(p2, 0), to_f16x8(p2, 1)}};
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pa[nb][0], o[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pa[nb][1], o[nb], 0, 0, 0);
+                return;
+            }
+            else if constexpr (ABL == 0 && PREC == PREC_BF16X3) {     // (the measurement variants remove parts of the hand-placed form below)
                 // split-bf16 operands: the four products of these rows, then the three weighted sums, each set issued with its
                 // accumulation chains interleaved (no matrix instruction depends on its predecessor): 45.5 us against 48.3 us for
                 // the hand-placed order below (ADX_ATTN_G_ABLATE=16), same bits
@@ -746,6 +824,7 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
                 mma_x3_interleaved<3>(A3, B3, o);
                 return;
             }
+            if constexpr (MIX == 0) {
             const f32x16 s0 = (ABL & 4) ? g16 : mma<PREC>(gop, qsh[0][lane], zero16());
             __builtin_amdgcn_sched_barrier(0);
             // the other products of these rows (18 matrix instructions), with block 0's vector work between them
@@ -778,6 +857,7 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((ABL & 2) != 0) o[2][0] += (float)p2.h[0][0] + (float)vop.h[0][1]; else o[2] = mma<PREC>(vop, p2, o[2]);
+            }
         };
         if (32 * t + 32 > a.L) group(std::true_type{});          // wave-uniform: the item's last group
         else group(std::false_type{});
@@ -825,12 +905,12 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
 size_t enc_rows_image_bytes() { return sizeof(float) * IMG_F32_FLOATS + sizeof(unsigned short) * IMG_BF_SHORTS; }
 
 hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W2, const float* Wkv, const float* Wq, void* image,
-                                hipStream_t stream) {
+                                hipStream_t stream, int f16_mats) {
     ImageSrc s;
     s.W[0] = Wo; s.W[1] = W1; s.W[2] = W2; s.W[3] = Wkv; s.W[4] = Wq;
     float* f = reinterpret_cast<float*>(image);
     unsigned short* b = reinterpret_cast<unsigned short*>(f + IMG_F32_FLOATS);
-    hipLaunchKernelGGL(build_image_kernel, dim3(8), dim3(256), 0, stream, s, f, b);
+    hipLaunchKernelGGL(build_image_kernel, dim3(8), dim3(256), 0, stream, s, f, b, f16_mats);
     return hipGetLastError();
 }
 
@@ -843,7 +923,7 @@ hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
+hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream, int mix) {
     if (a0.B <= 0 || a0.L <= 0 || !a0.image || !a0.packed || !a0.att0 || !a0.x0_time || (int64_t)a0.B * a0.L >= (int64_t)1 << 31) return hipErrorInvalidValue;
     EncRowsArgs a = a0;
     if (a.q1_item_stride == 0) a.q1_item_stride = (int64_t)a.L * a.ldq1;
@@ -893,6 +973,14 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream) {
 #endif
     if (a.gates && !a.gpk) return hipErrorInvalidValue;          // the gate table exists for the LayerNorm-row form only
     if (!a.gpk && !a.kv) return hipErrorInvalidValue;
+    if (mix) {                                                   // the image must hold Wo, W1 and W2 as fp16; always three resident waves per SIMD
+        if (prec != PREC_BF16X3 || mix != 7 || (a.gates && !a.gpk) || (!a.gpk && !a.kv)) return hipErrorInvalidValue;
+        const int blocks3 = (int)std::min<int64_t>((tiles + 3) / 4, 256 * 3);
+        if (a.gpk && a.gates) hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, true, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
+        else if (a.gpk) hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, false, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
+        else hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, false, false, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
+        return hipGetLastError();
+    }
     if (prec == PREC_F32) ADX_LAUNCH_ROWS(PREC_F32);
     else if (prec == PREC_BF16) ADX_LAUNCH_ROWS(PREC_BF16);
     else ADX_LAUNCH_ROWS(PREC_BF16X3);
@@ -915,7 +1003,7 @@ size_t enc_rows_g_bytes(int B, int L) { return (size_t)(((int64_t)B * L + 31) / 
 
 bool attention_g_ok(int n_keep) { return n_keep >= 1 && n_keep * NH <= AG_COLS; }
 
-hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream) {
+hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream, int mix) {
     AttnGArgs a = a0;
     if (a.q1_item_stride == 0) a.q1_item_stride = (int64_t)a.L * a.ldq1;
     if (a.B <= 0 || a.L <= 0 || !attention_g_ok(a.n_keep) || a.n_keep > a.L || !a.gpk || !a.image || !a.vecs || !a.wk || !a.q1 || !a.O ||
@@ -923,6 +1011,12 @@ hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream) {
         return hipErrorInvalidValue;
     const float* img_f32 = reinterpret_cast<const float*>(a.image);
     const unsigned short* img_bf = reinterpret_cast<const unsigned short*>(img_f32 + IMG_F32_FLOATS);
+    if (mix) {
+        if (prec != PREC_BF16X3) return hipErrorInvalidValue;
+        if (mix & 2) hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 3>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        else hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 1>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        return hipGetLastError();
+    }
     if (prec == PREC_F32) hipLaunchKernelGGL(attn_g_kernel<PREC_F32>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
     else if (prec == PREC_BF16) hipLaunchKernelGGL(attn_g_kernel<PREC_BF16>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
     else {

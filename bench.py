@@ -72,13 +72,14 @@ def time_kernel(fn, iters=20):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
-def pmc_counters(kernel_prefix="enc_rows_ke"):
+def pmc_counters(kernel_prefix="enc_rows_ke", precision="bf16x3"):
     """Per-launch hardware counters of one kernel from the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc_refiner.txt,
     collected at B = 1024 scenarios = 828 416 conditioning rows in separate passes per counter group).  Counter collection needs the
     profiler, so this run reads the committed figures and scales them by the row count; the line names the file."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_refiner.txt")))
+    suffix = "" if precision == "bf16x3" else "_" + precision           # counters are per kernel form: one file per precision
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_refiner{suffix}.txt")))
     if not files:
         return None, {}
     out, cur = {}, None
@@ -108,7 +109,7 @@ def enc_rows_write_bytes_per_row(fs):
     return 128 if (fs + 1) * N_HEAD <= 96 else 256
 
 
-def roofline(da, B, step):
+def roofline(da, B, step, precision="bf16x3"):
     """Dominant kernel of a denoiser call: the fused encoder row pipeline (enc_rows_kernel), one launch per call.
 
     It streams every conditioning row once -- 416 algorithmic bytes per row (288 read, 128 written), B * 809 rows per
@@ -141,9 +142,10 @@ def roofline(da, B, step):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None, "bytes_per_launch": algo, "launch_us": round(t["enc_rows"] * 1e6, 1),
             "launches_timed": launches, "stages_us": {n: round(v * 1e6, 1) for n, v in t.items()},
-            "note": "HBM is the binding one of the two roofs the contract offers, but the kernel is limited by vector issue (see `issue`): with "
-                    "no HBM traffic at all (no stores, inputs from L2) it still takes 80 of its 96 us (profiles/r02_enc_rows_ablation.txt)"}
-    src, pmc = pmc_counters()
+            "note": "HBM is the binding one of the two roofs the contract offers; the split-bf16 form of the kernel is limited by vector issue (see `issue`): "
+                    "with no HBM traffic at all (no stores, inputs from L2) it still takes 80 of its 96 us (profiles/r02_enc_rows_ablation.txt); the fp16 form "
+                    "issues a quarter fewer vector and a third of the matrix instructions and sits correspondingly closer to the memory roof"}
+    src, pmc = pmc_counters(precision=precision)
     same_form = wr == 128 and rd == 288 and FS == 10          # the kernel form the counters were collected on
     if same_form and "TCC_EA0_RDREQ_sum" in pmc and "TCC_EA0_WRREQ_sum" in pmc:
         # HBM bytes = read requests x 128 B (FETCH_SIZE doubled: the gfx950 correction) + write requests x 64 B, scaled by rows
@@ -534,14 +536,17 @@ def main():
     ap.add_argument("--n-sample", type=int, default=0, help="refiner: sampling steps (default 50; equal to --n-train = DDPM loop)")
     ap.add_argument("--mc-num", type=int, default=1, help="DiT workloads: samples per scenario (--batch counts trajectories)")
     ap.add_argument("--dit-steps", type=int, default=0, help="override the number of diffusion steps of a DiT workload (profiling)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32", "f16x2", "f16"],
-                    help="f16x2 / f16 (DiT workloads): fp16 operand planes, two / one matrix instructions per product")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "bf16", "fp32", "f16x2", "f16"],
+                    help="default: f16 for the refiner (its per-step kernels on fp16 operands, the rest split-bf16), bf16x3 for the other workloads; "
+                         "f16x2 / f16 on the DiT workloads: fp16 operand planes, two / one matrix instructions per product")
     ap.add_argument("--with-refiner", action="store_true", help="str workload: also time phase 1 + refiner end to end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the knee and dit_gemm measurements (profiling runs)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise launch, sharding and gather with gloo on the CPU")
     args = ap.parse_args()
 
+    if args.precision is None:
+        args.precision = "f16" if args.workload == "refiner" else "bf16x3"
     if args.gpus < 1:
         raise SystemExit("--gpus must be positive")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -620,7 +625,7 @@ def main():
         line = {
             "metric": "denoised trajectories/sec (8s, 80-pt)", "value": round(total * args.steps / dt, 2), "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "fp32", "f16": "f16"}.get(args.precision, "bf16"), "data": "synthetic",
             "config": {"workload": f"strDiffDiT-style refiner (enc/dec Transformer d=32, {L_COND} cond tokens), frame_stack {FS} x {80 // FS} chunks, "
                                    + (f"DDIM {N_SAMPLE} of {N_TRAIN} steps" if N_SAMPLE < N_TRAIN else f"DDPM {N_TRAIN} steps")
                                    + ", random init, synthetic nuPlan-shaped conditioning",
@@ -628,18 +633,30 @@ def main():
                        "parallelism": f"dp{world}",
                        "precision": {"bf16x3": "bf16 MFMA on split (hi+lo) operands, 3 MFMAs per product, f32 accumulate; trajectory path and scheduler f32",
                                      "bf16": "bf16 MFMA operands, f32 accumulate; trajectory path and scheduler f32",
+                                     "f16": "split-bf16 engine whose two per-step kernels over all conditioning rows (encoder row pipeline, last encoder attention) "
+                                            "multiply operands rounded once to fp16: one f16 MFMA per product, f32 accumulate; per-chunk caches and the "
+                                            "memory-row maps of the tail split-bf16 (3 MFMAs per product); trajectory path and scheduler f32",
                                      "fp32": "f32 MFMA"}[args.precision]},
         }
         if FS == 10:                                             # the fused kernels the roofline entry describes need T + 1 <= 16
-            line["roofline"] = roofline(da, B, sample)           # rank 0 only: the pass runs no collective
+            line["roofline"] = roofline(da, B, sample, args.precision)           # rank 0 only: the pass runs no collective
     if world == 1 and not args.no_extras and not args.batch and FS == 10:
         B2 = 4096
         dt2, sample2 = measure(B2, 3, 1)
         knee = {"batch_per_gpu": B2, "value": round(B2 * 3 / dt2, 2), "unit": "trajectories/s", "ms_per_step": round(dt2 / 3 * 1e3, 3),
                 "note": "same workload at 4x the configured batch: every per-step kernel fills the 256 CUs"}
-        r2 = roofline(da, B2, sample2)
+        r2 = roofline(da, B2, sample2, args.precision)
         knee["roofline_frac"], knee["launch_us"] = r2["frac"], r2["launch_us"]
         line["knee"] = knee
+        if args.precision != "bf16x3":           # the same workload with every product on split-bf16 operands, for comparison
+            da_main, da = da, build_model(dev, "bf16x3")
+            dt3, sample3 = measure(B, 3, 1)
+            r3 = roofline(da, B, sample3, "bf16x3")
+            line["bf16x3"] = {"value": round(B * 3 / dt3, 2), "unit": "trajectories/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "roofline_frac": r3["frac"],
+                              "launch_us": r3["launch_us"], "stages_us": r3["stages_us"],
+                              "note": "precision bf16x3 (3 bf16 MFMAs per product everywhere): ADE against fp32 5e-4 m median / 1.4e-3 m worst over 1024 "
+                                      "scenarios; the headline precision: 1.1e-3 / 3.7e-3 m (gate 1e-2 m, profiles/ade_mixed.py)"}
+            da = da_main
         line["dit_gemm"] = dit_gemm(dev)
         line["train_step"] = train_step(dev)
     if rank == 0:

@@ -711,7 +711,9 @@ def test_full_size_properties(dev):
 def test_bf16_final_ade(dev, sampler):
     """bf16-MFMA engine against the fp32 oracle, same noise: final trajectories within 1e-2 m ADE.
 
-    Gated mode: "bf16x3" (bf16 MFMA on split operands), the mode bench.py runs.  Weights follow the reference's
+    Gated modes: "bf16x3" (bf16 MFMA on split operands) and "f16" (the split-bf16 engine whose two per-step kernels over all
+    conditioning rows multiply operands rounded once to fp16: one matrix instruction per product, 11 significand bits against
+    bf16's 8), the mode bench.py runs.  Weights follow the reference's
     own initialisation (N(0, 0.02) matrices, zero biases).  With an untrained network the sampler is not
     contractive -- the first cosine step computes x0 = 160 (x - eps) -- so a relative error of 1e-3 in eps, which
     is what single-pass bf16 operands give, already moves the final trajectory by centimetres to decimetres;
@@ -722,7 +724,7 @@ def test_bf16_final_ade(dev, sampler):
     N, n_sample = (10, None) if sampler == "ddpm10" else (100, 50)
     n_draw = N if n_sample is None else n_sample
     res, ref = {}, None
-    for prec in ("bf16x3", "bf16"):
+    for prec in ("bf16x3", "f16", "bf16"):
         da = _make_da(fs, N, prec, "reference", dev, n_sample)
         noise = synth.noise(B, (8, n_draw), (fs, 4), NSEED).to(dev)
         out = da.generate(trajectory_prior=synth.trajectory_prior(B, ISEED).to(dev), maps_info=synth.maps_info(B, ISEED).to(dev),
@@ -731,7 +733,53 @@ def test_bf16_final_ade(dev, sampler):
             ref = _oracle_generate(da, B, fs, N, n_sample)
         res[prec] = float(metrics.ade_fde(out, ref)["ade8"].max())
     print(f"{sampler}: ADE vs fp32 oracle, max over scenarios [m]: {res}")
-    assert res["bf16x3"] < 1e-2
+    assert res["bf16x3"] < 1e-2 and res["f16"] < 1e-2
+
+
+def test_refiner_f16_engine(dev):
+    """precision="f16" of the refiner: every product of the per-step row kernel (attention out-projection, both FFN products) and of
+    the last encoder attention (scores, V, weighted sums) with both operands rounded once to fp16, everything else as split-bf16.
+    At 1024 scenarios of the bench configuration (DDIM 50 of 100): ADE against the fp32 engine on the same noise inside the 1e-2 m
+    gate for EVERY scenario with a factor two in hand, bit-identical re-run, rows independent of their batch; the configurations
+    whose row kernel takes other forms (no gate table; chunks longer than 11 frames) agree with the split-bf16 engine to the
+    same level; the MM-DiT engine refuses the precision."""
+    from autodiffusion_amd import _lib, dit, metrics, synth
+    fs, N, ns, B = 10, 100, 50, 1024
+    maps, prior = synth.maps_info(B, ISEED).to(dev), synth.trajectory_prior(B, ISEED).to(dev)
+    noise = synth.noise(B, (8, ns), (fs, 4), NSEED).to(dev)
+    out = {}
+    for prec in ("fp32", "bf16x3", "f16"):
+        da = _make_da(fs, N, prec, "reference", dev, ns)
+        out[prec] = da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"].clone()
+        if prec == "f16":
+            assert torch.equal(out[prec], da.generate(trajectory_prior=prior, maps_info=maps, noise=noise)["traj_logits"])
+            lo = B - 3
+            part = da.generate(trajectory_prior=prior[lo:].contiguous(), maps_info=maps[lo:].contiguous(), noise=noise[:, :, lo:].contiguous())["traj_logits"]
+            assert torch.equal(out[prec][lo:], part)
+    a3 = metrics.ade_fde(out["bf16x3"], out["fp32"])["ade8"]
+    ah = metrics.ade_fde(out["f16"], out["fp32"])["ade8"]
+    print(f"refiner B={B}: ADE vs fp32 engine, bf16x3 median {float(a3.median()):.2e} max {float(a3.max()):.2e} m; f16 median {float(ah.median()):.2e} "
+          f"max {float(ah.max()):.2e} m")
+    assert float(a3.max()) < 1e-2 and float(ah.max()) < 5e-3
+    assert not torch.equal(out["f16"], out["bf16x3"])                     # the fp16 kernels did run
+    # other forms of the row kernel: in-kernel fold instead of the gate table; whole-trajectory chunks (K | V projection + few-query attention)
+    small = {}
+    for tag, fs2, env in (("no gate table", 10, {"ADX_GATE_TABLE_MAX_MB": "0"}), ("frame stack 80", 80, {})):
+        for prec in ("bf16x3", "f16"):
+            os.environ.update(env)
+            try:
+                da = _make_da(fs2, 10, prec, "reference", dev, None)
+                nz = synth.noise(8, (80 // fs2, 10), (fs2, 4), NSEED).to(dev)
+                small[prec] = da.generate(trajectory_prior=prior[:8].contiguous(), maps_info=maps[:8].contiguous(), noise=nz)["traj_logits"].clone()
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        ade = float(metrics.ade_fde(small["f16"], small["bf16x3"])["ade8"].max())
+        print(f"  {tag}: ADE f16 vs bf16x3 {ade:.2e} m")
+        assert bool(torch.isfinite(small["f16"]).all()) and 0 < ade < 1e-2
+    with pytest.raises(_lib.AdxError):
+        mm = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "MM-DiT", diffusion_timesteps=4, precision="f16")).to(dev).eval()
+        mm.model.model(torch.zeros(2, 80, 4, device=dev), torch.zeros(2, device=dev, dtype=torch.long), torch.zeros(2, 80, 64, device=dev))
 
 
 # ------------------------------------------------------------------ variant B
@@ -1184,7 +1232,7 @@ def test_dit_fp16_plane_engines(dev, prec):
     """The fp16 precisions of the DiT engine at the smallest width whose products run on operand planes (hidden 512, 2 blocks,
     128 scenarios): one denoiser call against the fp32 engine (the error is the fp16 rounding of the weights, 2^-12 relative,
     through 2 blocks), a 4-step stochastic loop finite and repeatable; at a batch too small for any operand-plane product the
-    engine IS the split-bf16 engine, bit for bit; the MM-DiT engine and the refiner refuse the precision."""
+    engine IS the split-bf16 engine, bit for bit; the MM-DiT engine refuses the precision, the refiner the two-instruction one."""
     from autodiffusion_amd import _lib, dit, refiner, synth
     B, N = 128, 4
     out = {}
@@ -1211,9 +1259,10 @@ def test_dit_fp16_plane_engines(dev, prec):
     with pytest.raises(_lib.AdxError):
         mm = dit.DiffusionDecoder(dit.dit_config(64, 2, 4, "MM-DiT", diffusion_timesteps=N, precision=prec)).to(dev).eval()
         mm.model.model(torch.zeros(2, 80, 4, device=dev), torch.zeros(2, device=dev, dtype=torch.long), torch.zeros(2, 80, 64, device=dev))
-    with pytest.raises(_lib.AdxError):
-        da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=10, diffusion_timesteps=10, precision=prec)).to(dev).eval()
-        da.generate(trajectory_prior=synth.trajectory_prior(2, ISEED).to(dev), maps_info=synth.maps_info(2, ISEED).to(dev))
+    if prec == "f16x2":             # the refiner engine has the one-instruction form only (test_refiner_f16_engine)
+        with pytest.raises(_lib.AdxError):
+            da = refiner.DiffusionAugmentation(refiner.refiner_config(frame_stack=10, diffusion_timesteps=10, precision=prec)).to(dev).eval()
+            da.generate(trajectory_prior=synth.trajectory_prior(2, ISEED).to(dev), maps_info=synth.maps_info(2, ISEED).to(dev))
 
 
 @pytest.mark.parametrize("backbone", ["DiT", "MM-DiT"])
