@@ -174,6 +174,7 @@ struct EncRowsArgs {
                                                      // `packed` holds the 8-vector layout that goes with it
     float4* gpk = nullptr;                           // when set: NO K/V projection; the layer-1 LayerNorm rows are stored instead, in
                                                      // lane order gpk[(tile * 4 + g) * 64 + lane] (128 B per row, enc_rows_g_bytes), for attention_g
+    int prio = 0;                                    // wave priority the kernel raises itself to (0: leave it): the tail of the previous step runs beside it
     float* x1 = nullptr;                             // [B*L][32] layer-1 residual input, rows r < n_keep only
     float* q1 = nullptr; int64_t ldq1 = 0;           // layer-1 queries, rows r < n_keep only: row r of item b at q1[b * q1_item_stride + r * ldq1]
     int64_t q1_item_stride = 0;                      // 0: L * ldq1 (the rows of a [B*L][ldq1] buffer)
@@ -185,13 +186,13 @@ hipError_t enc_rows_build_image(const float* Wo, const float* W1, const float* W
                                 hipStream_t stream, int f16_mats = 0);   // f16_mats: bit m = the 16-bit fragments of matrix m (Wo, W1, W2, Wkv, Wq) hold fp16 (the mixed modes of enc_rows)
 size_t enc_rows_packed_bytes(int B, int L);
 hipError_t enc_rows_pack(const EncRowsArgs& a, hipStream_t stream);      // once per chunk: x0/q/state -> packed
-hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream, int mix = 0);  // once per step; mix (split-bf16 mode, gate table), fp16 products: 1 second FFN product, 2 out-projection, 4 first FFN product
+hipError_t enc_rows(const EncRowsArgs& a, int prec, hipStream_t stream, int mix = 0);  // once per step; mix (split-bf16 mode): 7 = the three products on fp16 operands, 15 = also half-width inputs and output (gate table)
 size_t enc_rows_g_bytes(int B, int L);
 // Gate-table form (once per chunk instead of enc_rows_pack): packed <- x0 and o / l in lane order, gates[step][tile][lane] <- the
 // fold gates of every step (tq: [n_steps][96] per-step q | k | v rows of the time token).  A step then passes
 // gates + step * (enc_rows_gates_bytes(B, L, 1) / 16) in EncRowsArgs::gates.
 size_t enc_rows_gates_bytes(int B, int L, int n_steps);
-hipError_t enc_rows_pack_gates(const EncRowsArgs& a, float4* gates, const float* tq, int n_steps, hipStream_t stream);
+hipError_t enc_rows_pack_gates(const EncRowsArgs& a, float4* gates, const float* tq, int n_steps, hipStream_t stream, bool half = false);   // half: fp16 o / l and gates (enc_rows mix 15)
 
 // Last encoder layer's attention of the n_keep visible rows of every item (n_keep * 8 heads <= 96) over ALL L rows of the item,
 // straight from the LayerNorm rows that enc_rows stored (gpk): keys and values are projected per 32-row tile on the matrix
@@ -206,9 +207,10 @@ struct AttnGArgs {
     float* O = nullptr; int64_t ldo = 0, o_batch_stride = 0;
     int B = 0, L = 0, n_keep = 0;
     float scale = 1.f;
+    int prio = 0;                                    // as EncRowsArgs::prio
 };
 bool attention_g_ok(int n_keep);
-hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream, int mix = 0);     // mix (split-bf16 mode): 1 weighted sums in fp16, 3 scores and V too
+hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream, int mix = 0);     // mix (split-bf16 mode): 1 weighted sums in fp16, 3 scores and V too, 7 the rows arrive as fp16
 
 // out[i, :] = [sin(t_i w), cos(t_i w)], w_j = 1e4^(-j/(dim/2-1))
 hipError_t timestep_embedding(const int64_t* t, int n, int dim, float* out, int64_t ldo, hipStream_t stream);

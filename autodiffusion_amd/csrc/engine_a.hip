@@ -73,7 +73,8 @@ struct EngineA final : adx_engine {
     float *GT = nullptr;                      // [n_steps][tiles][64] float4: the fold gates of every step of the chunk (gate-table form of the row kernel)
     bool gate_table = false;
     int mix = 0;               // products with both operands rounded once to fp16 (set at finalize): 1 | 16 | 32 the row kernel's second FFN product, out-projection and
-                               // first FFN product, 2 the weighted sums of the last encoder attention, 4 its scores and V (with 2)
+                               // first FFN product, 2 the weighted sums of the last encoder attention, 4 its scores and V (with 2), 8 (with all of them and the gate table) fp16 o / l,
+                               // gates and LayerNorm rows in memory
     float *Q1C = nullptr;                     // [2][B][T + 1][d] layer-1 queries of the visible rows, by step parity (LayerNorm-row attention)
     hipStream_t side_stream = nullptr, att_stream = nullptr;
     hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_att[2] = {nullptr, nullptr};
@@ -221,7 +222,7 @@ struct EngineA final : adx_engine {
             const std::string p0 = "encoder.layers.0", p1 = "encoder.layers.1";
             // engines created with ADX_PREC_F16 (cfg.precision reads ADX_PREC_BF16X3): every product of the two per-step kernels that
             // walk all conditioning rows with both operands rounded once to fp16.  ADX_A_MIX (measurement knob, read here) picks a subset.
-            mix = f16_single ? 55 : 0;
+            mix = f16_single ? 63 : 0;
             if (const char* mx = getenv("ADX_A_MIX")) { if (cfg.precision == ADX_PREC_BF16X3) mix = atoi(mx); }
             if ((mix & 0x31) && (mix & 0x31) != 0x31) mix &= ~0x31;       // the row kernel has one mixed instance: all three products or none
             ADX_HIP(enc_rows_build_image(P(p0 + ".self_attn.out_proj.weight"), P(p0 + ".linear1.weight"), P(p0 + ".linear2.weight"),
@@ -433,7 +434,7 @@ struct EngineA final : adx_engine {
             ADX_HIP(attention(at, s));
         }
         if (fused) {
-            if (gate_table) ADX_HIP(enc_rows_pack_gates(rows_args(B, 0), reinterpret_cast<float4*>(GT), tqkv0, (int)steps.size(), s));
+            if (gate_table) ADX_HIP(enc_rows_pack_gates(rows_args(B, 0), reinterpret_cast<float4*>(GT), tqkv0, (int)steps.size(), s, half_io()));
             else ADX_HIP(enc_rows_pack(rows_args(B, 0), s));
             // the time token's attention for every step of the chunk in one pass over the keys
             RowsAttnArgs tr;
@@ -447,6 +448,13 @@ struct EngineA final : adx_engine {
 
     float4* g_rows(int B, int par) const { return reinterpret_cast<float4*>(KV1) + (int64_t)par * (int64_t)(enc_rows_g_bytes(B, L) / sizeof(float4)); }
 
+    // wave priority of the two kernels of a step that walk all rows (tuning knob ADX_A_PRIO, read per call)
+    // default: 3 for the fp16 engines -- their waves then issue ahead of the tail's, which has slack: 58.9 -> 57.5 ms per generate at 1024
+    // scenarios, same bits -- and 0 for the others (the split-bf16 kernels leave the tail no slack: 79.6 -> 82.8 ms with 3)
+    int step_prio() const { const char* e = getenv("ADX_A_PRIO"); return e ? atoi(e) : (mix ? 3 : 0); }
+    bool half_io() const { return (mix & 8) && (mix & 0x31) == 0x31 && (mix & 6) == 6 && gate_table && attn_g; }
+    int rows_mix() const { return ((mix & 0x31) == 0x31 ? 7 : 0) | (half_io() ? 8 : 0); }
+
     EncRowsArgs rows_args(int B, int step, int par = 0) const {
         EncRowsArgs r;
         r.x0 = X0; r.q = QKV0; r.ldq = 3 * d; r.state = ST; r.packed = reinterpret_cast<const float4*>(PK);
@@ -457,10 +465,11 @@ struct EngineA final : adx_engine {
         r.kv = KV1; r.ldkv = 2 * d; r.x1 = par ? XB : XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
         if (attn_g) {       // the LayerNorm rows (128 B per row) take the place of K | V (256 B); they and the queries are double-buffered by step parity
             r.gpk = g_rows(B, par);
-            if (gate_table) r.gates = reinterpret_cast<const float4*>(GT) + (int64_t)step * (int64_t)(enc_rows_gates_bytes(B, L, 1) / sizeof(float4));
+            if (gate_table) r.gates = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(GT) + (int64_t)step * (int64_t)(enc_rows_gates_bytes(B, L, 1) / (half_io() ? 2 : 1)));
             r.q1 = Q1C + (int64_t)par * B * (T + 1) * d; r.ldq1 = d; r.q1_item_stride = (int64_t)(T + 1) * d;
         }
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
+        r.prio = step_prio();
         return r;
     }
 
@@ -511,7 +520,8 @@ struct EngineA final : adx_engine {
             g.q1 = Q1C + (int64_t)par * B * (T + 1) * d; g.ldq1 = d; g.q1_item_stride = (int64_t)(T + 1) * d;
             g.O = par ? ATTb : ATT; g.ldo = d; g.o_batch_stride = (int64_t)L * d;
             g.B = B; g.L = L; g.n_keep = T + 1; g.scale = 1.0f / sqrtf((float)(d / H));
-            ADX_HIP(attention_g(g, cfg.precision, s, (mix >> 1) & 3));
+            g.prio = step_prio();
+            ADX_HIP(attention_g(g, cfg.precision, s, ((mix >> 1) & 3) | (half_io() ? 4 : 0)));
         } else {
             ADX_HIP(attention_few_queries(fused_attn_args(B, par), s));
         }
@@ -562,7 +572,7 @@ struct EngineA final : adx_engine {
         if (step >= 0 && fused) {
             // layer 0 and layer 1 up to its attention: three launches
             prof_begin(1, s);
-            ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s, (mix & 1) | ((mix >> 3) & 6)));
+            ADX_HIP(enc_rows(rows_args(B, step), cfg.precision, s, rows_mix()));
             prof_end(s);
             prof_begin(2, s);
             ADX_TRY(last_attention(B, 0, s));
@@ -679,7 +689,7 @@ struct EngineA final : adx_engine {
         for (int it = 0; it < iters; ++it) {
             if (stage == 0) ADX_TRY(time_token_attention(B, 0, s));
             else if (stage == 1) {
-                ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s, (mix & 1) | ((mix >> 3) & 6)));
+                ADX_HIP(enc_rows(rows_args(B, 0), cfg.precision, s, rows_mix()));
             } else if (stage == 2) ADX_TRY(last_attention(B, 0, s));
             else if (stage == 3) {
                 if (!tail_ok && !tail_mfma_ok) { set_error("debug_stage: tail kernel not available for this shape"); return ADX_EINVAL; }
@@ -765,7 +775,7 @@ struct EngineA final : adx_engine {
                     z = noise + (int64_t)(1 + zi) * n;
                 }
                 if (k >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
-                ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s, (mix & 1) | ((mix >> 3) & 6)));
+                ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s, rows_mix()));
                 if (overlap_streams >= 3 && attn_g) {
                     // the row kernel of step k + 1 does not wait for this attention: its outputs (rows, queries, residual rows)
                     // go to the other parity, and the buffers of this parity are free again once the tail of step k is done

@@ -335,10 +335,45 @@ __device__ __forceinline__ void land_row(RowInG& in) {
     asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "+v"(p[8]));
 }
 
+// Half-width form of the same inputs and of the output (the fp16 mode only: every one of these values is rounded to fp16 by the
+// product that consumes it anyway): o / l as sixteen fp16 per lane (two 16-byte vectors), the four gates as fp16 (8 bytes), the
+// LayerNorm rows stored as fp16 -- x0 (128) + o / l (64) + gates (16) read and 64 written = 272 B per row instead of 416.
+struct RowInH {
+    float4 x[4];      // x0 features 8g + 4h .. +3 (the residual stream stays fp32)
+    uint4 o[2];       // o / l of heads 2g + h as fp16: values 4g + i in order
+    uint2 gate;       // gates of heads h, 2 + h, 4 + h, 6 + h as fp16
+};
+constexpr int PACK_VECS_H = 6;        // 16-byte vectors per lane per tile
+
+__device__ __forceinline__ void load_row(RowInH& in, const float4* __restrict__ p, const uint2* __restrict__ gp) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) in.x[g] = ld_stream(p + 64 * g);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p + 64 * (4 + v)));
+        in.o[v] = make_uint4(t.x, t.y, t.z, t.w);
+    }
+    const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2*>(gp));
+    in.gate = make_uint2(t.x, t.y);
+}
+
+__device__ __forceinline__ void land_row(RowInH& in) {
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    v4* p = reinterpret_cast<v4*>(in.x);
+    u4* o = reinterpret_cast<u4*>(in.o);
+    u2* g = reinterpret_cast<u2*>(&in.gate);
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(o[0]), "+v"(o[1]), "+v"(g[0]));
+}
+
 // One thread per (tile, lane): the step-independent inputs in lane order (x0, o / l) and, for every step of the schedule,
 // the gates of the lane's four heads: g = 1 / (1 + 2^(c - s)), c = m + log2 l of the cached state, s the scaled score of the
 // step's time-token key against the row's layer-0 query -- the very expressions of the in-kernel fold, so both forms of the
 // row kernel return the same bits.  tq: the per-step q | k | v rows of the time token ([n_steps][96], keys at +32).
+template <bool HALF>     // HALF: the layout of RowInH (o / l and the gates as fp16)
 __global__ __launch_bounds__(256) void pack_gates_kernel(const EncRowsArgs a, float4* __restrict__ packed, float4* __restrict__ gates, int64_t n_tiles,
                                                          const float* __restrict__ tq, int n_steps, float sc) {
     constexpr int CH = 128;                                   // steps staged in LDS at a time
@@ -353,19 +388,31 @@ __global__ __launch_bounds__(256) void pack_gates_kernel(const EncRowsArgs a, fl
     float4 q[4];
     float c[4];
     {
-        float4* dst = packed + tile * (PACK_VECS_G * 64) + lane;
+        float4* dst = packed + tile * ((HALF ? PACK_VECS_H : PACK_VECS_G) * 64) + lane;
         const float4* sp = reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24);      // 96 bytes: 4 x {m, l, o[4]}
         float st[24];
 #pragma unroll
         for (int v = 0; v < 6; ++v) { const float4 t = sp[v]; st[4 * v] = t.x; st[4 * v + 1] = t.y; st[4 * v + 2] = t.z; st[4 * v + 3] = t.w; }
+        _Float16 oh[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             q[g] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * g);
             const float inv = rcp_fast(st[6 * g + 1]);
             c[g] = st[6 * g] + __builtin_amdgcn_logf(st[6 * g + 1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) oh[4 * g + k] = f16_sat(st[6 * g + 2 + k] * inv);
             if (live) {
                 dst[64 * g] = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * g);
-                dst[64 * (4 + g)] = make_float4(st[6 * g + 2] * inv, st[6 * g + 3] * inv, st[6 * g + 4] * inv, st[6 * g + 5] * inv);
+                if constexpr (!HALF) dst[64 * (4 + g)] = make_float4(st[6 * g + 2] * inv, st[6 * g + 3] * inv, st[6 * g + 4] * inv, st[6 * g + 5] * inv);
+            }
+        }
+        if constexpr (HALF) {
+            if (live) {
+                f16x8 lo, hi;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { lo[k] = oh[k]; hi[k] = oh[8 + k]; }
+                reinterpret_cast<f16x8*>(dst)[64 * 4] = lo;
+                reinterpret_cast<f16x8*>(dst)[64 * 5] = hi;
             }
         }
     }
@@ -385,6 +432,12 @@ __global__ __launch_bounds__(256) void pack_gates_kernel(const EncRowsArgs a, fl
                 }
                 // streamed: written once here, read once by the step that uses it, 26 MB apart from its neighbours in time
                 typedef __attribute__((ext_vector_type(4))) float v4;
+                if constexpr (HALF) {
+                    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+                    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+                    const h4 gh = {(_Float16)gt[0], (_Float16)gt[1], (_Float16)gt[2], (_Float16)gt[3]};
+                    __builtin_nontemporal_store(__builtin_bit_cast(u2, gh), reinterpret_cast<u2*>(gates) + ((int64_t)(s0 + k) * n_tiles + tile) * 64 + lane);
+                } else
                 __builtin_nontemporal_store(v4{gt[0], gt[1], gt[2], gt[3]}, reinterpret_cast<v4*>(gates + ((int64_t)(s0 + k) * n_tiles + tile) * 64 + lane));
             }
         }
@@ -417,10 +470,12 @@ __device__ __forceinline__ void land_row(RowIn& in) {
 // ABL: measurement aid (results are wrong except for 16): 1 the FFN activation is the identity, 2 no FFN products, 4 no stores of
 // the row output, 8 every tile re-reads the wave's first tile (L2 hits instead of HBM), 16 GELU with unpacked FMAs (same bits)
 // MIX (split-bf16 mode only), bits: products with both operands rounded once to fp16 -- 1 the second FFN product, 2 the attention
-// out-projection, 4 the first FFN product (the image must have been built with the same matrices as fp16: bit m <-> matrix m of the image)
+// out-projection, 4 the first FFN product (the image must have been built with the same matrices as fp16: bit m <-> matrix m of the image);
+// 8 (with GOUT and GATES) the half-width inputs and output of RowInH
 template <int PREC, int WAVES, bool GOUT, bool GATES, int ABL = 0, int MIX = 0>
 __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel(const EncRowsArgs a) {
     constexpr int NT = WAVES == 4 ? 512 : 256;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* img = smem;                                                  // 49152 B
     float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats, then k0 (scaled) and v0
@@ -443,9 +498,12 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
     // projections), where few registers are live: the loads are in flight during a quarter of the tile time instead of
     // only while the wave waits for them, which is what keeps enough bytes in flight to use the HBM.
     const int64_t last_tile = (n_rows - 1) >> 5;
-    typename std::conditional<GATES, RowInG, RowIn>::type in;
+    constexpr bool HIO = (MIX & 8) != 0;
+    static_assert(!HIO || (GATES && GOUT), "the half-width form exists for the gate-table, LayerNorm-row kernel only");
+    typename std::conditional<HIO, RowInH, typename std::conditional<GATES, RowInG, RowIn>::type>::type in;
     auto fetch_row = [&](int64_t tile) {
-        if constexpr (GATES) load_row(in, a.packed + tile * (PACK_VECS_G * 64) + lane, a.gates + tile * 64 + lane);
+        if constexpr (HIO) load_row(in, a.packed + tile * (PACK_VECS_H * 64) + lane, reinterpret_cast<const uint2*>(a.gates) + tile * 64 + lane);
+        else if constexpr (GATES) load_row(in, a.packed + tile * (PACK_VECS_G * 64) + lane, a.gates + tile * 64 + lane);
         else load_row(in, a.packed + tile * (PACK_VECS * 64) + lane);
     };
     fetch_row(min((int64_t)wave_global, last_tile));
@@ -470,6 +528,21 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             typedef __attribute__((ext_vector_type(4))) float v4;
             v4* xp = reinterpret_cast<v4*>(in.x);
             asm volatile("" : "+v"(att), "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]));
+        } else if constexpr (HIO) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+            const h4 gt = __builtin_bit_cast(h4, in.gate);
+            const f16x8 ov[2] = {__builtin_bit_cast(f16x8, in.o[0]), __builtin_bit_cast(f16x8, in.o[1])};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 vv = *reinterpret_cast<const float4*>(v0s + 8 * g + 4 * h);
+                const float gg = (float)gt[g];
+                const float o0 = (float)ov[g >> 1][4 * (g & 1)], o1 = (float)ov[g >> 1][4 * (g & 1) + 1], o2 = (float)ov[g >> 1][4 * (g & 1) + 2],
+                            o3 = (float)ov[g >> 1][4 * (g & 1) + 3];
+                att[4 * g + 0] = fmaf(gg, vv.x - o0, o0);
+                att[4 * g + 1] = fmaf(gg, vv.y - o1, o1);
+                att[4 * g + 2] = fmaf(gg, vv.z - o2, o2);
+                att[4 * g + 3] = fmaf(gg, vv.w - o3, o3);
+            }
         } else if constexpr (GATES) {
             const float gt[4] = {in.gate.x, in.gate.y, in.gate.z, in.gate.w};
 #pragma unroll
@@ -577,7 +650,11 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         }
         // Lanes past the last row hold a copy of it (the packed tile repeats it) and store the same values to the same
         // place: the stores are unconditional, so exactly eight vector-memory operations follow the loads of the next tile.
-        if constexpr (GOUT) {
+        if constexpr (HIO) {
+            f16x8* gp = reinterpret_cast<f16x8*>(a.gpk) + (tile0 >> 5) * (2 * 64) + lane;
+            gp[0] = to_f16x8(gn, 0);
+            gp[64] = to_f16x8(gn, 1);
+        } else if constexpr (GOUT) {
             float4* gp = a.gpk + (tile0 >> 5) * (4 * 64) + lane;
             if constexpr ((ABL & 4) != 0) { if (gn[0] == 123.456f) gp[0] = make_float4(gn[0], gn[1], gn[2], gn[3]); } else
 #pragma unroll
@@ -689,9 +766,10 @@ constexpr float AG_NEG = -1.0e30f;
 //                          maximum, sum and rescale factor per LANE, because a column lives on a lane in S^T and in O^T alike.
 // Only the four features of a column's own head are meaningful in O^T; they are picked at the end.
 // MIX (split-bf16 mode only), bits: 1 the weighted sums O^T += V^T P^T with V and P rounded once to fp16; 2 also the scores and V
-// from g, the folded queries and Wv rounded once to fp16
+// from g, the folded queries and Wv rounded once to fp16; 4 (with 2) the LayerNorm rows arrive as fp16, as the half-width row kernel stores them
 template <int PREC, int ABL = 0, int MIX = 0>      // ABL: measurement aid (results are wrong except for 16): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights, 16 hand-placed instruction order
 __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     __shared__ float mrg[(6 + 48) * 64];
     __shared__ Opnd<PREC> qsh[3][64];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h2 = lane >> 5;
@@ -741,19 +819,32 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
     const int n_groups = (a.L + 31) >> 5;
     int t = wave;
     float4 gv[4];
+    f16x8 gq[2];                                                 // the same rows as fp16 (MIX & 4)
+    static_assert((MIX & 4) == 0 || (MIX & 2) != 0, "fp16 rows feed the fp16 products only");
     auto fetch = [&](int grp) {
         const int64_t row = min(r0 + 32 * (int64_t)min(grp, n_groups - 1) + n, r1 - 1);
-        const float4* gp = a.gpk + (row >> 5) * (4 * 64) + h2 * 32 + (row & 31);
+        if constexpr ((MIX & 4) != 0) {
+            const f16x8* gp = reinterpret_cast<const f16x8*>(a.gpk) + (row >> 5) * (2 * 64) + h2 * 32 + (row & 31);
+            gq[0] = gp[0]; gq[1] = gp[64];
+        } else {
+            const float4* gp = a.gpk + (row >> 5) * (4 * 64) + h2 * 32 + (row & 31);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gv[g] = gp[64 * g];          // written by the row kernel just before: kept cacheable (streamed loads measured 1 % slower)
+            for (int g = 0; g < 4; ++g) gv[g] = gp[64 * g];      // written by the row kernel just before: kept cacheable (streamed loads measured 1 % slower)
+        }
     };
     fetch(t);
     for (; t < n_groups; t += 2) {
-        f32x16 g16;
+        f32x16 g16 = zero16();
+        f16x8 gh[2] = {};
+        if constexpr ((MIX & 4) != 0) { gh[0] = gq[0]; gh[1] = gq[1]; }
+        else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { g16[4 * g] = gv[g].x; g16[4 * g + 1] = gv[g].y; g16[4 * g + 2] = gv[g].z; g16[4 * g + 3] = gv[g].w; }
+            for (int g = 0; g < 4; ++g) { g16[4 * g] = gv[g].x; g16[4 * g + 1] = gv[g].y; g16[4 * g + 2] = gv[g].z; g16[4 * g + 3] = gv[g].w; }
+            if constexpr ((MIX & 2) != 0) { gh[0] = to_f16x8(g16, 0); gh[1] = to_f16x8(g16, 1); }
+        }
         fetch(t + 2);                                                   // next group (clamped: the last iteration re-reads and drops it)
-        const Opnd<PREC> gop = to_opnd<PREC>(g16);
+        Opnd<PREC> gop;
+        if constexpr ((MIX & 2) == 0) gop = to_opnd<PREC>(g16);
         // One group, as straight-line code (the masked form of the item's last group is a second copy): a wavefront issues
         // in order, so vector work hides under matrix work only where the two alternate in the instruction stream.
         auto group = [&](auto partial_c) {
@@ -785,7 +876,6 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
             if constexpr (MIX != 0) {                                  // one fp16 instruction per weighted sum and 16 keys
                 f32x16 acc4[4] = {zero16(), zero16(), zero16(), zero16()};
                 if constexpr ((MIX & 2) != 0) {                        // scores and V from fp16 operands as well
-                    const f16x8 gh[2] = {to_f16x8(g16, 0), to_f16x8(g16, 1)};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -974,8 +1064,12 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream, int mix
     if (a.gates && !a.gpk) return hipErrorInvalidValue;          // the gate table exists for the LayerNorm-row form only
     if (!a.gpk && !a.kv) return hipErrorInvalidValue;
     if (mix) {                                                   // the image must hold Wo, W1 and W2 as fp16; always three resident waves per SIMD
-        if (prec != PREC_BF16X3 || mix != 7 || (a.gates && !a.gpk) || (!a.gpk && !a.kv)) return hipErrorInvalidValue;
+        if (prec != PREC_BF16X3 || (mix != 7 && mix != 15) || (a.gates && !a.gpk) || (!a.gpk && !a.kv)) return hipErrorInvalidValue;
         const int blocks3 = (int)std::min<int64_t>((tiles + 3) / 4, 256 * 3);
+        if (mix == 15) {                                         // half-width inputs (enc_rows_pack_gates with half = true) and output
+            if (!a.gpk || !a.gates) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, true, 0, 15>), dim3(blocks3), dim3(256), smem, stream, a);
+        } else
         if (a.gpk && a.gates) hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, true, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
         else if (a.gpk) hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, false, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
         else hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, false, false, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
@@ -991,11 +1085,13 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream, int mix
 
 size_t enc_rows_gates_bytes(int B, int L, int n_steps) { return (size_t)(((int64_t)B * L + 31) / 32) * 64 * sizeof(float4) * (size_t)n_steps; }
 
-hipError_t enc_rows_pack_gates(const EncRowsArgs& a, float4* gates, const float* tq, int n_steps, hipStream_t stream) {
+hipError_t enc_rows_pack_gates(const EncRowsArgs& a, float4* gates, const float* tq, int n_steps, hipStream_t stream, bool half) {
     if (a.B <= 0 || a.L <= 0 || !a.packed || !a.x0 || !a.q || !a.state || !gates || !tq || n_steps <= 0) return hipErrorInvalidValue;
     const int64_t tiles = ((int64_t)a.B * a.L + 31) / 32, n = tiles * 64;
-    hipLaunchKernelGGL(pack_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, const_cast<float4*>(a.packed), gates, tiles, tq, n_steps,
-                       a.scale * LOG2E_F);
+    if (half) hipLaunchKernelGGL(pack_gates_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, const_cast<float4*>(a.packed), gates, tiles, tq,
+                                 n_steps, a.scale * LOG2E_F);
+    else hipLaunchKernelGGL(pack_gates_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, const_cast<float4*>(a.packed), gates, tiles, tq,
+                            n_steps, a.scale * LOG2E_F);
     return hipGetLastError();
 }
 
@@ -1013,7 +1109,9 @@ hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream, int mi
     const unsigned short* img_bf = reinterpret_cast<const unsigned short*>(img_f32 + IMG_F32_FLOATS);
     if (mix) {
         if (prec != PREC_BF16X3) return hipErrorInvalidValue;
-        if (mix & 2) hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 3>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        if ((mix & 6) == 6) hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 7>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        else if (mix & 4) return hipErrorInvalidValue;
+        else if (mix & 2) hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 3>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
         else hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 1>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
         return hipGetLastError();
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ADE of the refiner's split-bf16 engine and of its fp16 forms (ADX_A_MIX bits: 1 | 16 | 32 = 49 the three products of the row kernel with both
-operands rounded once to fp16, 2 | 4 = 6 the weighted sums, scores and V of the last encoder attention; 55 = all of them = precision "f16")
+operands rounded once to fp16, 2 | 4 = 6 the weighted sums, scores and V of the last encoder attention; 55 = all of them; 63 = also fp16 o / l, gates and LayerNorm rows in memory = precision "f16")
 against the fp32 engine over many scenarios, for the bench configuration (frame stack 10, DDIM 50 of 100, reference initialisation); and
 the time of one generate() for each.  (The product library has the row kernel's three products as one instance; r03_ade_mixed*.txt were
 taken while each product had its own.)
@@ -40,7 +40,7 @@ def run(prec, mix):
 
 
 ref, _ = run("fp32", 0)
-for mix in (0, 6, 49, 55, 0, 55):
+for mix in (0, 6, 49, 55, 63, 0, 63):
     out, dt = run("bf16x3", mix)
     ade = metrics.ade_fde(out, ref)["ade8"]
     q = torch.quantile(ade, torch.tensor([0.5, 0.9, 0.99]))
