@@ -126,7 +126,8 @@ class SinusoidalPosEmb(nn.Module):
 
 
 class Transformer(nn.Module):
-    """Encoder/decoder denoiser.  Constructor arguments as in the reference; ``precision`` ("fp32" | "bf16" | "bf16x3")
+    """Encoder/decoder denoiser.  Constructor arguments as in the reference; ``precision`` ("fp32" | "bf16" | "bf16x3" | "f16":
+    the split-bf16 engine whose two per-step kernels over all conditioning rows multiply operands rounded once to fp16)
     and ``elide`` (skip mask-unobservable work) select the engine build."""
 
     def __init__(self, input_dim: int, output_dim: int, horizon: int, n_cond_steps: int = None, cond_dim: int = 0,

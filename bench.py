@@ -95,24 +95,36 @@ def pmc_counters(kernel_prefix="enc_rows_ke", precision="bf16x3"):
 
 PMC_ROWS = 1024 * 809           # conditioning rows of the launch the committed counters were collected on
 SIMDS, CLOCK_GHZ = 1024, 2.4    # 256 CUs x 4 SIMDs; peak engine clock
-def enc_rows_read_bytes_per_row(B, n_steps):
-    """x0 (128) + the cached attention output o / l (128) + this step's gates (32) while the per-chunk gate table fits the
-    engine's budget (its rule, ADX_GATE_TABLE_MAX_MB included); otherwise x0 + layer-0 query (128) + normalised state (160)."""
+def gate_table_fits(B, n_steps):
+    """The engine's rule for the per-chunk gate table (ADX_GATE_TABLE_MAX_MB included)."""
     budget = int(os.environ.get("ADX_GATE_TABLE_MAX_MB", "16384")) << 20
     need = n_steps * ((B * L_COND + 31) // 32) * 1024
-    return 288 if 0 < need <= budget else 416
+    return 0 < need <= budget
 
 
-def enc_rows_write_bytes_per_row(fs):
-    """The layer-1 LayerNorm row (128 B) while the visible rows fit the matrix-core attention ((fs + 1) x 8 heads <= 96);
-    layer-1 K | V (256 B) for longer chunks, whose last attention reads stored keys and values."""
-    return 128 if (fs + 1) * N_HEAD <= 96 else 256
+def enc_rows_read_bytes_per_row(B, n_steps, fs, precision="bf16x3"):
+    """x0 (128) + the cached attention output o / l (128) + this step's gates (32) while the per-chunk gate table fits the
+    engine's budget; otherwise x0 + layer-0 query (128) + normalised state (160).  The fp16 engine keeps o / l and the gates as
+    fp16 (64 + 16) when it has the gate table and the LayerNorm-row attention."""
+    if not gate_table_fits(B, n_steps):
+        return 416
+    return 208 if precision == "f16" and (fs + 1) * N_HEAD <= 96 else 288
+
+
+def enc_rows_write_bytes_per_row(B, n_steps, fs, precision="bf16x3"):
+    """The layer-1 LayerNorm row (128 B; 64 B as fp16 in the fp16 engine with the gate table) while the visible rows fit the
+    matrix-core attention ((fs + 1) x 8 heads <= 96); layer-1 K | V (256 B) for longer chunks, whose last attention reads stored
+    keys and values."""
+    if (fs + 1) * N_HEAD > 96:
+        return 256
+    return 64 if precision == "f16" and gate_table_fits(B, n_steps) else 128
 
 
 def roofline(da, B, step, precision="bf16x3"):
     """Dominant kernel of a denoiser call: the fused encoder row pipeline (enc_rows_kernel), one launch per call.
 
-    It streams every conditioning row once -- 416 algorithmic bytes per row (288 read, 128 written), B * 809 rows per
+    It streams every conditioning row once -- 416 algorithmic bytes per row (288 read, 128 written; 272 = 208 + 64 in the fp16
+    engine, which keeps o / l, gates and its output as fp16), B * 809 rows per
     launch -- and does 18.4 kflop per row on the matrix cores, so of the two roofs HBM bandwidth is the one that binds
     (43 us at 8 TB/s against 6 us at the dense bf16 MFMA peak, B = 1024); what actually limits the kernel is vector
     issue (GELU and operand conversions: profiles/r02_enc_rows_ablation.txt).  Its launches are timed inside one more pass of the workload: the engine brackets
@@ -134,8 +146,9 @@ def roofline(da, B, step, precision="bf16x3"):
     finally:
         eng.profile(False)
     rows = B * L_COND
-    wr = enc_rows_write_bytes_per_row(FS)
-    rd = enc_rows_read_bytes_per_row(B, N_SAMPLE if N_SAMPLE < N_TRAIN else N_TRAIN)
+    n_steps = N_SAMPLE if N_SAMPLE < N_TRAIN else N_TRAIN
+    wr = enc_rows_write_bytes_per_row(B, n_steps, FS, precision)
+    rd = enc_rows_read_bytes_per_row(B, n_steps, FS, precision)
     algo = float((rd + wr) * rows)
     achieved = algo / t["enc_rows"] / 1e9
     line = {"kernel": "enc_rows_kernel (encoder layer 0 after its attention + layer 1 LayerNorm over all conditioning rows)", "bound": "hbm",
@@ -146,7 +159,7 @@ def roofline(da, B, step, precision="bf16x3"):
                     "with no HBM traffic at all (no stores, inputs from L2) it still takes 80 of its 96 us (profiles/r02_enc_rows_ablation.txt); the fp16 form "
                     "issues a quarter fewer vector and a third of the matrix instructions and sits correspondingly closer to the memory roof"}
     src, pmc = pmc_counters(precision=precision)
-    same_form = wr == 128 and rd == 288 and FS == 10          # the kernel form the counters were collected on
+    same_form = (wr, rd) == ((64, 208) if precision == "f16" else (128, 288)) and FS == 10          # the kernel form the counters were collected on
     if same_form and "TCC_EA0_RDREQ_sum" in pmc and "TCC_EA0_WRREQ_sum" in pmc:
         # HBM bytes = read requests x 128 B (FETCH_SIZE doubled: the gfx950 correction) + write requests x 64 B, scaled by rows
         line["traffic"] = round((pmc["TCC_EA0_RDREQ_sum"] * 128 + pmc["TCC_EA0_WRREQ_sum"] * 64) * rows / PMC_ROWS)

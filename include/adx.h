@@ -40,7 +40,12 @@ enum { ADX_PREC_F32 = 0, ADX_PREC_BF16 = 1, ADX_PREC_BF16X3 = 2,
         * saturate at +-65504. */
        ADX_PREC_F16X2 = 3,
        /* the same with the activations rounded once to fp16 as well: one plane per operand, one matrix instruction per product,
-        * 2^-12 relative per operand.  Every other kernel of such an engine still runs as ADX_PREC_BF16X3. */
+        * 2^-12 relative per operand.  Every other kernel of such an engine still runs as ADX_PREC_BF16X3.
+        * Also a precision of the refiner engine (ADX_VARIANT_A): every product of its two per-step kernels that walk all
+        * conditioning rows -- the encoder row pipeline (attention out-projection, both FFN products) and the last encoder attention
+        * (scores, values, weighted sums) -- multiplies operands rounded once to fp16, one matrix instruction per product, and the
+        * tensors those kernels exchange through memory (cached attention outputs, gates, LayerNorm rows) are stored as fp16; the
+        * per-chunk caches, the tail and the scheduler run as under ADX_PREC_BF16X3. */
        ADX_PREC_F16 = 4 };
 enum { ADX_VARIANT_A = 0, ADX_VARIANT_DIT = 1, ADX_VARIANT_MMDIT = 2 };
 

@@ -93,3 +93,16 @@ if [ $part = all ] || [ $part = f16 ]; then
     timeout -k 10 400 python3 bench.py --workload dit1024 --precision f16 --dit-steps 20 --steps 2 --warmup 1 > $O/bench_dit1024_f16.json 2>> $O/bench.err
     trace dit1024_f16 python3 bench.py --workload dit1024 --precision f16 --mc-num 16 --dit-steps 10 --steps 1 --warmup 1
 fi
+if [ $part = f16 ]; then     # the refiner's fp16 precision (bench default): bench line, traces, counter passes of its per-step kernels
+    timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > $O/bench_b1024_f16.json 2> $O/bench_f16.err && cut -c1-300 $O/bench_b1024_f16.json
+    trace refiner_f16_b1024 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+    ADX_NO_OVERLAP=1 trace refiner_f16_b1024_one_stream python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+    rm -f $O/pmc_refiner_f16.txt
+    echo "# rocprofv3 --pmc passes over profiles/stage_times.py f16 1024 (B=1024: 828416 conditioning rows), per-launch averages" > $O/pmc_refiner_f16.txt
+    echo "# HBM bytes = TCC_EA0_RDREQ x 128 B (= FETCH_SIZE KB doubled, the gfx950 correction) + TCC_EA0_WRREQ x 64 B" >> $O/pmc_refiner_f16.txt
+    pmc pmc_refiner_f16 "TCC_EA0_RDREQ_sum FETCH_SIZE" "enc_rows attn_g tail_mfma" python3 profiles/stage_times.py f16 1024
+    pmc pmc_refiner_f16 "TCC_EA0_WRREQ_sum WRITE_SIZE" "enc_rows attn_g tail_mfma" python3 profiles/stage_times.py f16 1024
+    pmc pmc_refiner_f16 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "enc_rows attn_g tail_mfma" python3 profiles/stage_times.py f16 1024
+    cat $O/pmc_refiner_f16.txt
+    python3 profiles/stage_times.py f16 1024 2>&1 | grep -v amdgpu.ids > $O/stage_times_f16.txt; cat $O/stage_times_f16.txt
+fi
