@@ -24,7 +24,6 @@ arithmetic.  Every arithmetic step is a libadx kernel (``adx_op_rmsnorm``, ``adx
 """
 from __future__ import annotations
 
-import re
 from types import SimpleNamespace
 from typing import Dict, List, Optional
 
