@@ -238,7 +238,7 @@ class NuplanRasterizeEncoder(nn.Module):
     def select_keypoints(self, info_dict):
         label = info_dict["trajectory_label"]
         if "specified" in self.use_key_points:
-            return label[:, self.selected_indices, :]
+            return torch.stack([label[:, i, :] for i in self.selected_indices], dim=1)      # slices, not an index tensor: nothing is uploaded (graph capture)
         if "universal" in self.use_key_points:
             return label[:, 19::20, :]
         assert False, "key points should be either specified or universal"

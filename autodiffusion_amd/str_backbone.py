@@ -357,3 +357,38 @@ class STR_Mixtral(nn.Module):
             traj = traj.flip(-2)
         pred["traj_logits"] = traj
         return pred
+
+
+class GraphedGenerate:
+    """``generate(**batch)`` of a phase-1 model replayed from a captured graph.  Phase 1 is ~1 200 operator launches composed on the
+    host, and at evaluation batch sizes their launch cost is most of its time; every one of them is enqueued on the current stream
+    without a host round trip (the expert block buckets its tokens on the device), so the whole call can be captured once per input
+    shape and replayed.  Inputs are copied into buffers the graph owns; the returned tensors belong to the graph and are overwritten
+    by the next call of the same shape (clone what must outlive it)."""
+
+    def __init__(self, model):
+        self.model = model
+        self._graphs: Dict[tuple, tuple] = {}
+
+    @torch.no_grad()
+    def __call__(self, **batch):
+        tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        other = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())) + tuple(sorted((k, repr(v)) for k, v in other.items()))
+        if key not in self._graphs:
+            static_in = {k: v.detach().clone() for k, v in tensors.items()}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                  # warm-up: weights prepared, kernel attributes set, workspaces sized
+                self.model.generate(**static_in, **other)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.model.generate(**static_in, **other)
+            self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = self._graphs[key]
+        for k, v in tensors.items():
+            static_in[k].copy_(v)
+        graph.replay()
+        return static_out

@@ -327,6 +327,9 @@ def bench_str(args, dev):
     dt, out = timed(lambda: model.generate(**batch))
     assert bool(torch.isfinite(out["traj_logits"]).all())
     enc_dt, _ = timed(lambda: model.encoder(is_training=False, **batch))
+    graphed = str_backbone.GraphedGenerate(model)
+    gdt, gout = timed(lambda: graphed(**batch))
+    assert torch.equal(gout["traj_logits"], out["traj_logits"])
     line = {
         "metric": "trajectory priors/sec (phase 1 of generate())", "value": round(B / dt, 2), "unit": "trajectories/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -336,6 +339,8 @@ def bench_str(args, dev):
                                "873 tokens per scenario, random init, synthetic rasters", "batch_per_gpu": B, "global_batch": B, "parallelism": "dp1",
                    "precision": prec},
         "stages_ms": {"raster_encoder": round(enc_dt * 1e3, 3), "decoder_and_heads": round((dt - enc_dt) * 1e3, 3)},
+        "graph_replay": {"ms_per_step": round(gdt * 1e3, 3), "value": round(B / gdt, 2), "unit": "trajectories/s",
+                         "note": "the same call captured once per input shape and replayed (str_backbone.GraphedGenerate): same bits"},
     }
     if not args.no_cpu_baseline:
         from oracle import str_backbone as osb

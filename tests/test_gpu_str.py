@@ -192,3 +192,47 @@ def test_op_attention_long_sequences(dev, B, H, Sq, Skv, dh, mask_off):
     e = rel_err(got, ref)
     print(f"attention B={B} H={H} Sq={Sq} Skv={Skv} dh={dh} mask_off={mask_off}: rel err {e:.1e}")
     assert e < 5e-6
+
+
+@pytest.mark.parametrize("key_points", ["no", "specified_two_backward"])
+def test_str_generate_other_key_point_settings(dev, key_points):
+    """generate() without key points (one decoder pass, the prior read from the trajectory slots) and with two key points, against
+    the CPU oracle on the same seeded weights (the oracle is pinned by the recording at five key points)."""
+    from autodiffusion_amd import str_backbone, synth
+    from oracle import str_backbone as osb
+    B = 2
+    cfg = str_backbone.str_config("mixtral-small", n_embd=64, n_layer=2, n_head=4, n_inner=128, num_key_value_heads=2, vit_intermediate_size=96,
+                                  use_key_points=key_points)
+    model = synth.fill_module_(str_backbone.STR_Mixtral(cfg), WSEED).eval()
+    batch = dict(high_res_raster=synth.occupancy_raster(B, 58, ISEED + 5), low_res_raster=synth.occupancy_raster(B, 58, ISEED + 6),
+                 context_actions=synth.noise(B, (), (4, 4), NSEED + 3) * torch.tensor([2.0, 0.3, 0.0, 0.1]), trajectory_label=synth.trajectory_prior(B, ISEED))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ocfg = dict(n_layer=2, n_head=4, n_kv_head=2, n_experts=8, top_k=2, rms_eps=1e-5, rope_theta=1e6)
+    sel = [] if key_points == "no" else [79, 4]
+    ref = osb.str_generate(sd, ocfg, batch["high_res_raster"], batch["low_res_raster"], batch["context_actions"], batch["trajectory_label"], sel)
+    out = model.to(dev).generate(**{k: v.to(dev) for k, v in batch.items()})
+    e = rel_err(out["traj_logits"].cpu(), ref["traj_logits"])
+    print(f"STR generate, key points {key_points!r}: traj_logits rel err {e:.1e}")
+    assert e < GATE and rel_err(out["maps_info"].cpu(), ref["maps_info"]) < GATE
+    if sel:
+        assert out["key_points_logits"].shape == (B, 2, 2) and rel_err(out["key_points_logits"].cpu(), ref["key_points_logits"]) < GATE
+    else:
+        assert "key_points_logits" not in out
+
+
+def test_str_generate_replayed_from_a_graph(dev, golden):
+    """The whole of phase 1 captured once and replayed: the same bits as the eager call, for new inputs of the same shape too."""
+    from autodiffusion_amd import str_backbone
+    g = golden("g21_str_generate")
+    model, _, batch = str_model_from_recording(g, "small")
+    model = model.to(dev)
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    eager = {k: v.clone() for k, v in model.generate(**batch).items()}
+    graphed = str_backbone.GraphedGenerate(model)
+    out = graphed(**batch)
+    assert all(torch.equal(out[k], eager[k]) for k in eager)
+    other = dict(batch, context_actions=batch["context_actions"] * 0.5, high_res_raster=batch["low_res_raster"], low_res_raster=batch["high_res_raster"])
+    eager2 = {k: v.clone() for k, v in model.generate(**other).items()}
+    out2 = graphed(**other)
+    assert len(graphed._graphs) == 1 and all(torch.equal(out2[k], eager2[k]) for k in eager2)
+    assert not torch.equal(eager2["traj_logits"], eager["traj_logits"])

@@ -447,3 +447,51 @@ def test_training_operators_reject_bad_arguments():
     assert lib.adx_op_attention_stats(fake, fake, fake, fake, fake, 2, 8, 200, 200, 64, C.c_float(0.5), -1, None) == 1   # 200 tokens: no LDS room
     assert lib.adx_op_group_colsum(fake, 70000, 80, 64, fake, None) == 1
     assert lib.adx_op_layernorm_bwd(fake, None, fake, 0, 32, C.c_float(1e-5), fake, None, None) == 1
+
+
+def test_mixtral_state_dict_layouts():
+    """MixtralModel holds its parameters under the names of a reference checkpoint (transformers 4.42.3: per-expert w1 / w2 / w3 under
+    block_sparse_moe); a state dict in the layout of newer transformers releases (fused mlp.experts.gate_up_proj / down_proj, mlp.gate)
+    loads into the same tensors; the size table and the refusals of STR_Mixtral follow build_models / the scope of this package."""
+    import torch
+    from autodiffusion_amd import str_backbone
+    m = str_backbone.MixtralModel(hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                                  num_local_experts=4, num_experts_per_tok=2, vocab_size=16)
+    names = set(m.state_dict().keys())
+    assert "layers.1.block_sparse_moe.experts.3.w2.weight" in names and "layers.0.block_sparse_moe.gate.weight" in names
+    assert "layers.0.self_attn.k_proj.weight" in names and m.state_dict()["layers.0.self_attn.k_proj.weight"].shape == (16, 32)
+    assert "norm.weight" in names and "embed_tokens.weight" in names and not any("bias" in n for n in names)
+    g = torch.Generator().manual_seed(0)
+    newer = {}
+    for k, v in m.state_dict().items():
+        if ".block_sparse_moe.experts." in k:
+            continue
+        newer[k.replace(".block_sparse_moe.gate.", ".mlp.gate.")] = torch.randn(v.shape, generator=g)
+    for i in range(2):
+        newer[f"layers.{i}.mlp.experts.gate_up_proj"] = torch.randn(4, 128, 32, generator=g)
+        newer[f"layers.{i}.mlp.experts.down_proj"] = torch.randn(4, 32, 64, generator=g)
+    want = {k: v.clone() for k, v in newer.items()}
+    m.load_state_dict(newer)
+    sd = m.state_dict()
+    for i in range(2):
+        for e in range(4):
+            p = f"layers.{i}.block_sparse_moe.experts.{e}."
+            assert torch.equal(sd[p + "w1.weight"], want[f"layers.{i}.mlp.experts.gate_up_proj"][e, :64])       # gate rows first ...
+            assert torch.equal(sd[p + "w3.weight"], want[f"layers.{i}.mlp.experts.gate_up_proj"][e, 64:])       # ... then up rows
+            assert torch.equal(sd[p + "w2.weight"], want[f"layers.{i}.mlp.experts.down_proj"][e])
+        assert torch.equal(sd[f"layers.{i}.block_sparse_moe.gate.weight"], want[f"layers.{i}.mlp.gate.weight"])
+    assert str_backbone.mixtral_sizes("scratch-mixtral-small-wide") == dict(n_layer=4, n_embd=512, n_inner=2048, n_head=8)
+    assert str_backbone.mixtral_sizes("mixtral-small") == dict(n_layer=4, n_embd=256, n_inner=1024, n_head=8)
+    assert str_backbone.mixtral_sizes("mixtral-3b-wide")["n_embd"] == 1536
+    with pytest.raises(AssertionError):
+        str_backbone.mixtral_sizes("gpt-small")
+    for bad in (dict(use_proposal=1), dict(autoregressive=True), dict(kp_tokenizer="cluster"), dict(task="waymo"), dict(kp_decoder_type="diffusion"),
+                dict(raster_encoder_type="resnet18")):
+        with pytest.raises(NotImplementedError):
+            str_backbone.STR_Mixtral(str_backbone.str_config("mixtral-small", n_layer=1, **bad))
+    with pytest.raises(ValueError):
+        str_backbone.MixtralModel(hidden_size=30, intermediate_size=64, num_hidden_layers=1, num_attention_heads=4)
+    # a module built from the configuration helper exposes the reference's sub-module names
+    model = str_backbone.STR_Mixtral(str_backbone.str_config("mixtral-small", n_layer=1, use_key_points="no"))
+    top = {n.split(".")[0] for n, _ in model.named_parameters()}
+    assert top == {"encoder", "transformer", "traj_decoder"}            # no key-point head without key points
