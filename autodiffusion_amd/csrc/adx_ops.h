@@ -280,7 +280,9 @@ struct TailMfmaArgs {
     float* model_out = nullptr;
     int B = 0, L = 0, T = 0, n_dec = 0;
     const float* pos = nullptr;       // pos_emb [T][32]: read from here when T + 1 > 16 (the table in `vecs` holds 16 rows)
-    int split = 0;                    // 1: the image was packed in the split-bf16 form (tail_mfma_pack_block(..., split = 1))
+    // arithmetic form the blocks were packed in (tail_mfma_pack_block(..., split)): `split` for the maps on memory rows, `traj` for
+    // the maps on trajectory tokens.  0 fp32, 1 split-bf16 (memory rows only), 2 split-fp16; supported pairs: (0,0) (1,0) (2,0) (2,2)
+    int split = 0, traj = 0;
 };
 struct TailMfmaVecLayout {
     int e_bo, e_ln2_g, e_ln2_b, e_b1, e_b2, din_b, pos, layer0, layer_size;

@@ -63,7 +63,8 @@ struct EngineA final : adx_engine {
     TailArgs tail_tpl;
     bool tail_mfma_ok = false;         // the one-wavefront-per-item MFMA form applies (in_dim = out_dim = 4)
     int maps_batch = -1;               // batch size of the last sample() call that embedded maps_info (ADX_FLAG_KEEP_MAPS)
-    int tail_split = 0;                // its maps on memory rows run on split-bf16 operands (bf16 precision modes) instead of fp32 MFMAs
+    int tail_split = 0;                // its maps run on split 16-bit operands (bf16 / fp16 precision modes) instead of fp32 MFMAs
+    int tail_mem = 0, tail_traj = 0;   // arithmetic form of the MFMA tail's maps on memory rows / trajectory tokens (TailMfmaArgs::split / traj)
     void* tailm_image = nullptr;
     float* tailm_vecs = nullptr;
     // The decoder-side kernel (tail) of step k only depends on the encoder-side kernels of step k and on x_k, and the
@@ -250,9 +251,16 @@ struct EngineA final : adx_engine {
         ADX_HIP(hipMemsetAsync(tailm_vecs, 0, sizeof(float) * tail_mfma_vec_floats(), s));
         const TailMfmaVecLayout v = tail_mfma_vec_layout();
         int blk = 0;
-        bool mem_side = true;              // blocks that act on memory rows take the split-bf16 form in the bf16 precision modes
+        // Forms (0 fp32, 1 split-bf16, 2 split-fp16): the fp32 engine (0, 0); the bf16 and fp16 engines (2, 2).
+        // ADX_TAIL_FORMS = "<memory><trajectory>" (two digits, tuning knob, read here) picks another supported pair: "10" is memory
+        // rows split-bf16 + trajectory tokens fp32, "20" the most accurate of the reduced forms.
+        tail_mem = tail_traj = tail_split ? 2 : 0;
+        if (const char* tf = getenv("ADX_TAIL_FORMS")) {
+            if (tail_split && tf[0] >= '0' && tf[0] <= '2' && tf[1] >= '0' && tf[1] <= '2') { tail_mem = tf[0] - '0'; tail_traj = tf[1] - '0'; }
+        }
+        bool mem_side = true;              // blocks that act on memory rows
         auto block = [&](const std::string& w, int ldw, int row0, int col0) {
-            return tail_mfma_pack_block(P(w), ldw, row0, col0, tailm_image, blk++, mem_side ? tail_split : 0, s);
+            return tail_mfma_pack_block(P(w), ldw, row0, col0, tailm_image, blk++, mem_side ? tail_mem : tail_traj, s);
         };
         auto vec = [&](const float* src, int off, int n) {
             return hipMemcpyAsync(tailm_vecs + off, src, sizeof(float) * n, hipMemcpyDeviceToDevice, s);
@@ -309,7 +317,7 @@ struct EngineA final : adx_engine {
         if (tail_mfma_ok) {
             TailMfmaArgs t;
             t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = par ? ATTb : ATT; t.x1 = par ? XB : XA; t.x = x; t.z = z; t.coef = coef;
-            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_split;
+            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_mem; t.traj = tail_traj;
             t.pos = P("pos_emb");
             ADX_HIP(tail_mfma(t, s));
             return ADX_OK;

@@ -17,7 +17,13 @@
 // holds are its 8 k-slots of the K = 32 MFMA, the weight image carries the matching permutation -- so LayerNorm, attention,
 // GELU and the scheduler update are the same fp32 code in both.  The split form applies to the maps on MEMORY rows only
 // (the encoder remainder and the cross-attention key / value projections, blocks packed with split = 1); the maps on
-// trajectory tokens stay fp32 in every mode.
+// trajectory tokens stay fp32 in the fp32 and split-bf16 modes.
+// A third form, split-fp16 (fp16 high + low halves, the same three MFMAs per output tile; 22 significand bits, so the products
+// are good to ~2^-21), is close enough to fp32 for the maps on trajectory tokens as well, which split-bf16 is not: it is the form of
+// EVERY map in the bf16 and fp16 engine modes (measured at 1024 scenarios of the bench configuration against memory rows split-bf16
+// + trajectory tokens fp32: 79.6 -> 76.7 ms per generate and ADE against the fp32 engine 5.0e-4 -> 4.7e-4 m median in the split-bf16
+// engine, 60.0 -> 56.0 ms and 1.09e-3 -> 1.06e-3 m in the fp16 engine).  Memory rows rounded ONCE to fp16 -- what the row kernel does
+// to every row of the first encoder layer in the fp16 engine -- fail here: 1.8e-2 m median.
 #include "adx_ops.h"
 #include "fastmath.h"
 
@@ -86,21 +92,38 @@ __device__ __forceinline__ f32x4 mfma4(const float4& w, const f32x4& x, f32x4 ac
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
-// An activation prepared as the B operand of a map: itself (fp32 form) or its bf16 high / low halves (split form).
-template <bool BF> struct Opnd { A8 x; };
-template <> struct Opnd<true> { bf16x8_t hi, lo; };
+// Arithmetic form of a map (the value of `split` its block was packed with)
+constexpr int F_F32 = 0, F_BF16X3 = 1, F_F16X3 = 2;
+// split-fp16: the low halves of both operands are stored times 2^11, which keeps them normal fp16 numbers whenever the value itself is
+// (unscaled, the low half of anything below 0.125 -- every weight -- is an fp16 subnormal, good to 3e-8 absolute only: measured
+// on the bench configuration, that alone moved the final trajectories by 6e-4 m)
+constexpr float LO_SCALE = 2048.f;
 
-template <bool BF>
-__device__ __forceinline__ Opnd<BF> prep(const A8& in) {
-    Opnd<BF> o;
-    if constexpr (BF) {
+// An activation prepared as the B operand of a map: itself (fp32 form) or its bf16 or fp16 high / low halves (split forms).
+template <int F> struct Opnd { A8 x; };
+template <> struct Opnd<F_BF16X3> { bf16x8_t hi, lo; };
+template <> struct Opnd<F_F16X3> { f16x8_t hi, lo; };
+
+template <int F>
+__device__ __forceinline__ Opnd<F> prep(const A8& in) {
+    Opnd<F> o;
+    if constexpr (F == F_BF16X3) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float v = in.t[j >> 2][j & 3];
             const __bf16 h = (__bf16)v;
             o.hi[j] = h;
             o.lo[j] = (__bf16)(v - (float)h);
+        }
+    } else if constexpr (F == F_F16X3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = in.t[j >> 2][j & 3];
+            const _Float16 h = (_Float16)v;
+            o.hi[j] = h;
+            o.lo[j] = (_Float16)((v - (float)h) * LO_SCALE);
         }
     } else {
         o.x = in;
@@ -109,12 +132,12 @@ __device__ __forceinline__ Opnd<BF> prep(const A8& in) {
 }
 
 // out = acc + W_block in   (32 inputs -> 32 outputs), next block of the stream.
-// Split form: slot 2 mt = high halves, slot 2 mt + 1 = low halves of the A fragment of output tile mt (8 bf16 per lane).
-template <bool BF>
-__device__ __forceinline__ A8 mm32(WStream& s, const Opnd<BF>& in, A8 acc) {
+// Split forms: slot 2 mt = high halves, slot 2 mt + 1 = low halves of the A fragment of output tile mt (8 bf16 / fp16 per lane).
+template <int F>
+__device__ __forceinline__ A8 mm32(WStream& s, const Opnd<F>& in, A8 acc) {
     float4 w[BLOCK_SLOTS];
     s.pop(w);
-    if constexpr (BF) {
+    if constexpr (F == F_BF16X3) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const bf16x8_t wh = __builtin_bit_cast(bf16x8_t, w[2 * mt]), wl = __builtin_bit_cast(bf16x8_t, w[2 * mt + 1]);
@@ -122,6 +145,19 @@ __device__ __forceinline__ A8 mm32(WStream& s, const Opnd<BF>& in, A8 acc) {
             acc.t[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, in.hi, acc.t[mt], 0, 0, 0);
             acc.t[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, in.hi, acc.t[mt], 0, 0, 0);
         }
+    } else if constexpr (F == F_F16X3) {
+        // the cross terms (both low halves carry the factor LO_SCALE) collect in accumulators of their own: four independent chains
+        const f16x8_t wh0 = __builtin_bit_cast(f16x8_t, w[0]), wl0 = __builtin_bit_cast(f16x8_t, w[1]);
+        const f16x8_t wh1 = __builtin_bit_cast(f16x8_t, w[2]), wl1 = __builtin_bit_cast(f16x8_t, w[3]);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 lo0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, in.lo, z, 0, 0, 0);
+        f32x4 lo1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, in.lo, z, 0, 0, 0);
+        acc.t[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh0, in.hi, acc.t[0], 0, 0, 0);
+        acc.t[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh1, in.hi, acc.t[1], 0, 0, 0);
+        lo0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl0, in.hi, lo0, 0, 0, 0);
+        lo1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl1, in.hi, lo1, 0, 0, 0);
+        acc.t[0] = acc.t[0] + lo0 * (1.0f / LO_SCALE);
+        acc.t[1] = acc.t[1] + lo1 * (1.0f / LO_SCALE);
     } else {
         acc.t[0] = mfma4(w[0], in.x.t[0], acc.t[0]);
         acc.t[1] = mfma4(w[2], in.x.t[0], acc.t[1]);
@@ -195,14 +231,14 @@ __device__ __forceinline__ A8 ln8(const A8& y, const float* g, const float* b, i
 }
 
 // FFN: y + W2 gelu(W1 h + b1) + b2, the hidden layer one 32-wide slice at a time (8 blocks of the stream)
-template <bool BF>
+template <int F>
 __device__ __forceinline__ A8 ffn(WStream& s, const A8& y, const A8& h, const float* b1, const float* b2, int q) {
     A8 acc = add8(y, bias8(b2, q));
-    const Opnd<BF> ho = prep<BF>(h);
+    const Opnd<F> ho = prep<F>(h);
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
-        const A8 f = gelu8(mm32<BF>(s, ho, bias8(b1 + 32 * blk, q)));
-        acc = mm32<BF>(s, prep<BF>(f), acc);
+        const A8 f = gelu8(mm32<F>(s, ho, bias8(b1 + 32 * blk, q)));
+        acc = mm32<F>(s, prep<F>(f), acc);
     }
     return acc;
 }
@@ -249,7 +285,8 @@ __device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int row, int
 // NW > 1: one batch item per workgroup of NW wavefronts; wavefront w owns rows 16 w .. 16 w + 15 of the item (memory rows
 //         and trajectory tokens alike), keys / values of all rows meet in one LDS tile and the workgroup barriers around
 //         each attention replace the wave-private ordering.  Rows past the end are clamped copies that nobody can see.
-template <bool BF, int NW>
+// MEM / TRJ: arithmetic form of the maps on memory rows / on trajectory tokens.
+template <int MEM, int TRJ, int NW>
 __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail_mfma_kernel(const TailMfmaArgs a) {
     constexpr int NT = NW == 1 ? 256 : 64 * NW;
     __shared__ __attribute__((aligned(16))) float vec[V_TOTAL];
@@ -282,9 +319,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail
             xm.t[t] = ld4(a.x1 + row * 32 + 16 * t + 4 * q);
         }
     }
-    xm = mm32<BF>(ws, prep<BF>(att), add8(xm, bias8(vec + V_E_BO, q)));
-    xm = ffn<BF>(ws, xm, ln8(xm, vec + V_E_LN2G, vec + V_E_LN2B, q), vec + V_E_B1, vec + V_E_B2, q);
-    const Opnd<BF> xmo = prep<BF>(xm);               // the memory rows feed the K/V projections of every decoder layer
+    xm = mm32<MEM>(ws, prep<MEM>(att), add8(xm, bias8(vec + V_E_BO, q)));
+    xm = ffn<MEM>(ws, xm, ln8(xm, vec + V_E_LN2G, vec + V_E_LN2B, q), vec + V_E_B1, vec + V_E_B2, q);
+    const Opnd<MEM> xmo = prep<MEM>(xm);               // the memory rows feed the K/V projections of every decoder layer
     // ---- decoder input: input_emb(x_t) + pos_emb
     const int nt = min(rb + n, T - 1);
     const float* xrow = a.x + ((int64_t)b * T + nt) * 4;
@@ -302,31 +339,31 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail
 #pragma unroll 1
     for (int l = 0; l < a.n_dec; ++l) {
         const float* lv = vec + V_LAYER0 + l * VL_SIZE;
-        // causal self-attention.  The maps on trajectory tokens are exact fp32 in both forms: the sampler multiplies an
+        // causal self-attention.  The maps on trajectory tokens are never split-bf16: the sampler multiplies an
         // error of the noise estimate by up to 1 / sqrt(alpha_bar) = 160 per step, and split-bf16 products there move the
         // final trajectory by millimetres (measured: ADE against the fp32 engine 3e-3 m median, 8e-3 m worst of 1024 scenarios,
-        // against 4e-4 / 8e-4 m with fp32 maps).
-        Opnd<false> h = prep<false>(ln8(y, lv + VL_LN1G, lv + VL_LN1B, q));
-        const A8 qs = mm32<false>(ws, h, bias8(lv + VL_BQKV, q));
-        const A8 ks = mm32<false>(ws, h, bias8(lv + VL_BQKV + 32, q));
-        const A8 vs = mm32<false>(ws, h, bias8(lv + VL_BQKV + 64, q));
+        // against 4e-4 / 8e-4 m with fp32 maps).  They are fp32, or split-fp16 (TRJ) in the fp16 engine.
+        Opnd<TRJ> h = prep<TRJ>(ln8(y, lv + VL_LN1G, lv + VL_LN1B, q));
+        const A8 qs = mm32<TRJ>(ws, h, bias8(lv + VL_BQKV, q));
+        const A8 ks = mm32<TRJ>(ws, h, bias8(lv + VL_BQKV + 32, q));
+        const A8 vs = mm32<TRJ>(ws, h, bias8(lv + VL_BQKV + 64, q));
         tile_sync();
         store_kv(kv + rb * KV_LD, ks, vs, n, q);
         tile_sync();
         A8 at = attend(kv, qs, rb + n, q, nk_self, 0);
-        y = mm32<false>(ws, prep<false>(at), add8(y, bias8(lv + VL_BO, q)));
+        y = mm32<TRJ>(ws, prep<TRJ>(at), add8(y, bias8(lv + VL_BO, q)));
         // cross-attention: query i sees memory rows 0..i+1; keys / values come from the memory rows (split form allowed)
-        h = prep<false>(ln8(y, lv + VL_LN2G, lv + VL_LN2B, q));
-        const A8 qc = mm32<false>(ws, h, bias8(lv + VL_BQ, q));
-        const A8 km = mm32<BF>(ws, xmo, bias8(lv + VL_BKV, q));
-        const A8 vm = mm32<BF>(ws, xmo, bias8(lv + VL_BKV + 32, q));
+        h = prep<TRJ>(ln8(y, lv + VL_LN2G, lv + VL_LN2B, q));
+        const A8 qc = mm32<TRJ>(ws, h, bias8(lv + VL_BQ, q));
+        const A8 km = mm32<MEM>(ws, xmo, bias8(lv + VL_BKV, q));
+        const A8 vm = mm32<MEM>(ws, xmo, bias8(lv + VL_BKV + 32, q));
         tile_sync();
         store_kv(kv + rb * KV_LD, km, vm, n, q);
         tile_sync();
         at = attend(kv, qc, rb + n, q, nk_cross, 1);
-        y = mm32<false>(ws, prep<false>(at), add8(y, bias8(lv + VL_BO2, q)));
+        y = mm32<TRJ>(ws, prep<TRJ>(at), add8(y, bias8(lv + VL_BO2, q)));
         // feed-forward
-        y = ffn<false>(ws, y, ln8(y, lv + VL_LN3G, lv + VL_LN3B, q), lv + VL_B1, lv + VL_B2, q);
+        y = ffn<TRJ>(ws, y, ln8(y, lv + VL_LN3G, lv + VL_LN3B, q), lv + VL_B1, lv + VL_B2, q);
     }
     // ---- ln_f, head (4 outputs: only the q == 0 lanes hold real ones), scheduler update
     const A8 hf = ln8(y, vec + V_LNFG, vec + V_LNFB, q);
@@ -353,8 +390,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail
 // One 32x32 block of W (row-major, leading dimension ldw) at (row0, col0) -> 4 slots of A fragments.
 // Rows >= n_rows and columns >= n_cols of the block are zero.
 //   fp32 form : slot mt * 2 + t = W[16 mt + m][16 t + 4 k + i], i = 0..3, for lane (m = lane & 15, k = lane >> 4)
-//   split form: slot mt * 2 = bf16 high halves, slot mt * 2 + 1 = low halves of W[16 mt + m][16 (j >> 2) + 4 k + (j & 3)],
-//               j = 0..7: the k-slot order in which a lane of the accumulator layout holds its 8 features
+//   split forms (split = 1 bf16, 2 fp16): slot mt * 2 = high halves, slot mt * 2 + 1 = low halves of
+//               W[16 mt + m][16 (j >> 2) + 4 k + (j & 3)], j = 0..7: the k-slot order in which a lane of the accumulator layout
+//               holds its 8 features
 __global__ void pack_block_kernel(const float* W, int ldw, int row0, int col0, int n_rows, int n_cols, float4* dst, int split) {
     const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;      // 256 threads
     const int mt = slot >> 1, t = slot & 1;
@@ -366,13 +404,22 @@ __global__ void pack_block_kernel(const float* W, int ldw, int row0, int col0, i
             v[i] = (r < n_rows && c < n_cols) ? W[(int64_t)(row0 + r) * ldw + col0 + c] : 0.f;
         }
         dst[slot * SLOT + lane] = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
+    } else if (split == F_BF16X3) {
         bf16x8_t f;
         for (int j = 0; j < 8; ++j) {
             const int c = 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
             const float w = (r < n_rows && c < n_cols) ? W[(int64_t)(row0 + r) * ldw + col0 + c] : 0.f;
             const __bf16 h = (__bf16)w;
             f[j] = t == 0 ? h : (__bf16)(w - (float)h);
+        }
+        dst[slot * SLOT + lane] = __builtin_bit_cast(float4, f);
+    } else {                    // fp16 high halves / low halves times LO_SCALE
+        f16x8_t f;
+        for (int j = 0; j < 8; ++j) {
+            const int c = 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+            const float w = (r < n_rows && c < n_cols) ? W[(int64_t)(row0 + r) * ldw + col0 + c] : 0.f;
+            const _Float16 h = (_Float16)w;
+            f[j] = t == 0 ? h : (_Float16)((w - (float)h) * LO_SCALE);
         }
         dst[slot * SLOT + lane] = __builtin_bit_cast(float4, f);
     }
@@ -419,20 +466,25 @@ hipError_t tail_mfma_pack_ends(const float* Win, const float* Whead, void* image
     return hipGetLastError();
 }
 
-template <bool BF>
+template <int MEM, int TRJ>
 static hipError_t launch_tail_mfma(const TailMfmaArgs& a, hipStream_t stream) {
     if (a.T + 1 <= 16) {
-        hipLaunchKernelGGL((tail_mfma_kernel<BF, 1>), dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((tail_mfma_kernel<MEM, TRJ, 1>), dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
     } else {
         if (!a.pos) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((tail_mfma_kernel<BF, 6>), dim3(a.B), dim3(384), 0, stream, a);
+        hipLaunchKernelGGL((tail_mfma_kernel<MEM, TRJ, 6>), dim3(a.B), dim3(384), 0, stream, a);
     }
     return hipGetLastError();
 }
 
 hipError_t tail_mfma(const TailMfmaArgs& a, hipStream_t stream) {
     if (a.B <= 0 || a.T <= 0 || a.T + 1 > 96 || a.n_dec < 0 || a.n_dec > 4 || !a.image || !a.vecs) return hipErrorInvalidValue;
-    return a.split ? launch_tail_mfma<true>(a, stream) : launch_tail_mfma<false>(a, stream);
+    // (form of the memory-row maps, form of the trajectory-token maps) the image was packed for
+    if (a.split == F_F32 && a.traj == F_F32) return launch_tail_mfma<F_F32, F_F32>(a, stream);
+    if (a.split == F_BF16X3 && a.traj == F_F32) return launch_tail_mfma<F_BF16X3, F_F32>(a, stream);
+    if (a.split == F_F16X3 && a.traj == F_F16X3) return launch_tail_mfma<F_F16X3, F_F16X3>(a, stream);
+    if (a.split == F_F16X3 && a.traj == F_F32) return launch_tail_mfma<F_F16X3, F_F32>(a, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace adx
