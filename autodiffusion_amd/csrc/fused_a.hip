@@ -46,6 +46,7 @@ constexpr float LOG2E_F = 1.4426950408889634f;
 constexpr int NFRAG_F32 = 16 * (1 + 4 + 4 + 2 + 1);      // 192 fragments of 256 B
 constexpr int NFRAG_BF = 2 * (1 + 4 + 4 + 2 + 1);        // 24 fragments of 1 KiB per half
 constexpr int IMG_F32_FLOATS = NFRAG_F32 * 64;           // 12288 floats = 49152 B
+constexpr int ROWS_LDS_IMG_H = (NFRAG_BF + 2) * 64 * 8 * 2;  // 26624 B: the LDS copy of the half-width row kernel (all high halves + one tile of low halves)
 constexpr int IMG_BF_SHORTS = 2 * NFRAG_BF * 64 * 8;     // hi + lo: 24576 shorts = 49152 B
 constexpr int VEC_FLOATS = 32 * 6 + 128 + 64 + 32;       // bo g2 be2 b2 g1 be1 (6 x 32) + b1 (128) + bkv (64) + bq (32) = 416
 
@@ -97,15 +98,17 @@ __global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short*
 }
 
 // ---- Y^T tile += W[mat][nt][it] X^T, input in accumulator layout ----------------------------------------------
+// lo_off: where the low halves of this tile's fragments live, in shorts from its high halves (the full image keeps all low halves
+// behind all high halves; the compact LDS copy of the half-width row kernel keeps only the one tile of low halves it needs)
 template <int PREC>
-__device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, const f32x16& in, f32x16 acc, int lane) {
+__device__ __forceinline__ f32x16 mm(const unsigned char* lds_img, int tile, const f32x16& in, f32x16 acc, int lane, int lo_off = NFRAG_BF * 64 * 8) {
     if constexpr (PREC == PREC_F32) {
         const float* w = reinterpret_cast<const float*>(lds_img) + tile * 16 * 64 + lane;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[reg * 64], in[reg], acc, 0, 0, 0);
     } else {
         const unsigned short* whi = reinterpret_cast<const unsigned short*>(lds_img) + (tile * 2 * 64 + lane) * 8;
-        const unsigned short* wlo = whi + NFRAG_BF * 64 * 8;
+        const unsigned short* wlo = whi + lo_off;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 bhv, blv;
@@ -479,12 +482,24 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
     constexpr int NT = WAVES == 4 ? 512 : 256;
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* img = smem;                                                  // 49152 B
-    float* vec = reinterpret_cast<float*>(smem + IMG_F32_FLOATS * 4);           // VEC_FLOATS floats, then k0 (scaled) and v0
+    constexpr bool HIO = (MIX & 8) != 0;
+    // LDS copy of the weight image: 49152 B, or ROWS_LDS_IMG_H for the half-width form, which reads the high halves (fp16 Wo, W1, W2 and
+    // bf16 Wq) and the low halves of Wq only -- that leaves room for the tail's workgroups on the same CU (three workgroups of this
+    // kernel with full images fill 147 of the 160 KB, and the tail, which runs beside it on the second stream, found no CU to start on)
+    constexpr int IMG_LDS = HIO ? ROWS_LDS_IMG_H : IMG_F32_FLOATS * 4;
+    constexpr int Q_LO_OFF = HIO ? 2 * 64 * 8 : NFRAG_BF * 64 * 8;              // low halves of Wq: the tile behind it / the full image's place
+    unsigned char* img = smem;
+    float* vec = reinterpret_cast<float*>(smem + IMG_LDS);                      // VEC_FLOATS floats, then k0 (scaled) and v0
     const float sc = a.scale * LOG2E_F;
     {
         const uint4* src = reinterpret_cast<const uint4*>(PREC == PREC_F32 ? (const void*)a.img_f32 : (const void*)a.img_bf);
         uint4* dst = reinterpret_cast<uint4*>(img);
+        if constexpr (HIO) {
+            constexpr int HI16 = NFRAG_BF * 64 * 8 * 2 / 16, TILE16 = 2 * 64 * 8 * 2 / 16;     // uint4 per region / per tile
+            static_assert(ROWS_LDS_IMG_H == (HI16 + TILE16) * 16, "compact image = all high halves + one tile of low halves");
+            for (int i = threadIdx.x; i < HI16; i += NT) dst[i] = src[i];
+            for (int i = threadIdx.x; i < TILE16; i += NT) dst[HI16 + i] = src[HI16 + tile_base(4) * TILE16 + i];
+        } else
         for (int i = threadIdx.x; i < IMG_F32_FLOATS / 4; i += NT) dst[i] = src[i];
         for (int i = threadIdx.x; i < VEC_FLOATS; i += NT) vec[i] = a.vecs[i];
         if (threadIdx.x < 64) vec[VEC_FLOATS + threadIdx.x] = a.key0[threadIdx.x] * (threadIdx.x < 32 ? sc : 1.0f);
@@ -500,7 +515,6 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
     // projections), where few registers are live: the loads are in flight during a quarter of the tile time instead of
     // only while the wave waits for them, which is what keeps enough bytes in flight to use the HBM.
     const int64_t last_tile = (n_rows - 1) >> 5;
-    constexpr bool HIO = (MIX & 8) != 0;
     static_assert(!HIO || (GATES && GOUT), "the half-width form exists for the gate-table, LayerNorm-row kernel only");
     typename std::conditional<HIO, RowInH, typename std::conditional<GATES, RowInG, RowIn>::type>::type in;
     auto fetch_row = [&](int64_t tile) {
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         const f32x16 gn = layer_norm32(y2, g1, be1, h);
         const bool keep = live && r < a.n_keep;     // rows the decoder can see: they also need the layer-1 residual and query
         if (__any(keep)) {                          // wave-uniform: ~1 tile in 25 holds the head of a batch item
-            const f32x16 q1 = mm<PREC>(img, tile_base(4), gn, zero16(), lane);
+            const f32x16 q1 = mm<PREC>(img, tile_base(4), gn, zero16(), lane, Q_LO_OFF);
             if (keep) {
                 float* xo = a.x1 + row * D;
                 float* qo = a.q1 + (int64_t)((unsigned)row / (unsigned)a.L) * a.q1_item_stride + (int64_t)r * a.ldq1;
@@ -1070,7 +1084,11 @@ hipError_t enc_rows(const EncRowsArgs& a0, int prec, hipStream_t stream, int mix
         const int blocks3 = (int)std::min<int64_t>((tiles + 3) / 4, 256 * 3);
         if (mix == 15) {                                         // half-width inputs (enc_rows_pack_gates with half = true) and output
             if (!a.gpk || !a.gates) return hipErrorInvalidValue;
-            hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, true, 0, 15>), dim3(blocks3), dim3(256), smem, stream, a);
+            // tuning knob: resident workgroups per CU of this form (its compact LDS image and 124 registers allow 4; the default 3
+            // leaves registers for a wave of the tail on every SIMD)
+            static const int wgs = [] { const char* e = getenv("ADX_ENC_ROWS_WGS"); const int v = e ? atoi(e) : 3; return v >= 1 && v <= 4 ? v : 3; }();
+            const int blocks_h = (int)std::min<int64_t>((tiles + 3) / 4, 256 * wgs);
+            hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, true, 0, 15>), dim3(blocks_h), dim3(256), ROWS_LDS_IMG_H + (VEC_FLOATS + 64) * 4, stream, a);
         } else
         if (a.gpk && a.gates) hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, true, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);
         else if (a.gpk) hipLaunchKernelGGL((enc_rows_kernel<PREC_BF16X3, 3, true, false, 0, 7>), dim3(blocks3), dim3(256), smem, stream, a);

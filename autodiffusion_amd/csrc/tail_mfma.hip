@@ -281,6 +281,47 @@ __device__ __forceinline__ A8 attend(const float* kv, const A8& qv, int row, int
     return o;
 }
 
+// The same attention when an item's rows fit one tile (at most 16 keys): the scores stay in registers, so the maximum is known
+// before the first exponential -- one exponential per (key, head) instead of the two of the running-maximum form and no rescaling
+// of the partial sums (13 vector instructions per key and head instead of 21, and the exponentials are quarter rate).
+__device__ __forceinline__ A8 attend16(const float* kv, const A8& qv, int row, int q, int nk, int mask_off) {
+    const float sc = 0.5f * LOG2E_M;
+    const f32x4 qs[2] = {qv.t[0] * sc, qv.t[1] * sc};
+    float s[2][16], m[2] = {-INFINITY, -INFINITY};
+    const int last = row + mask_off;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < nk) {                                   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 kk = ld4(kv + j * KV_LD + 4 * q + 16 * t);
+                const float v = fmaf(qs[t][0], kk[0], fmaf(qs[t][1], kk[1], fmaf(qs[t][2], kk[2], qs[t][3] * kk[3])));
+                s[t][j] = j <= last ? v : -INFINITY;
+                m[t] = fmaxf(m[t], s[t][j]);            // key 0 is visible to every row: m is finite
+            }
+        }
+    }
+    float l[2] = {0.f, 0.f};
+    A8 o;
+    o.t[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o.t[1] = o.t[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < nk) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 vv = ld4(kv + j * KV_LD + 4 * q + 32 + 16 * t);
+                const float p = exp2_fast(s[t][j] - m[t]);
+                l[t] += p;
+                o.t[t] = o.t[t] + vv * p;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) o.t[t] = o.t[t] * rcp_fast(l[t]);
+    return o;
+}
+
 // NW = 1: a workgroup of four wavefronts, one batch item each (at most 16 rows per item).
 // NW > 1: one batch item per workgroup of NW wavefronts; wavefront w owns rows 16 w .. 16 w + 15 of the item (memory rows
 //         and trajectory tokens alike), keys / values of all rows meet in one LDS tile and the workgroup barriers around
@@ -350,7 +391,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail
         tile_sync();
         store_kv(kv + rb * KV_LD, ks, vs, n, q);
         tile_sync();
-        A8 at = attend(kv, qs, rb + n, q, nk_self, 0);
+        A8 at = NW == 1 ? attend16(kv, qs, n, q, nk_self, 0) : attend(kv, qs, rb + n, q, nk_self, 0);
         y = mm32<TRJ>(ws, prep<TRJ>(at), add8(y, bias8(lv + VL_BO, q)));
         // cross-attention: query i sees memory rows 0..i+1; keys / values come from the memory rows (split form allowed)
         h = prep<TRJ>(ln8(y, lv + VL_LN2G, lv + VL_LN2B, q));
@@ -360,7 +401,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail
         tile_sync();
         store_kv(kv + rb * KV_LD, km, vm, n, q);
         tile_sync();
-        at = attend(kv, qc, rb + n, q, nk_cross, 1);
+        at = NW == 1 ? attend16(kv, qc, n, q, nk_cross, 1) : attend(kv, qc, rb + n, q, nk_cross, 1);
         y = mm32<TRJ>(ws, prep<TRJ>(at), add8(y, bias8(lv + VL_BO2, q)));
         // feed-forward
         y = ffn<TRJ>(ws, y, ln8(y, lv + VL_LN3G, lv + VL_LN3B, q), lv + VL_B1, lv + VL_B2, q);
