@@ -75,14 +75,15 @@ __global__ void build_image_kernel(ImageSrc src, float* img_f32, unsigned short*
     for (int mat = 0; mat < 5; ++mat)
         for (int nt = 0; nt < nt_count[mat]; ++nt)
             for (int it = 0; it < in_tiles(mat); ++it, ++tile) {
+                const float wscale = mat == 2 ? 0.5f : 1.0f;      // the row kernel's activation returns twice the GELU
                 for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 16 * 64; e += gridDim.x * blockDim.x) {
                     const int reg = e >> 6, l = e & 63;
-                    img_f32[(tile * 16 + reg) * 64 + l] = src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + 32 * it + feat(reg, l >> 5)];
+                    img_f32[(tile * 16 + reg) * 64 + l] = wscale * src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + 32 * it + feat(reg, l >> 5)];
                 }
                 for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * 64 * 8; e += gridDim.x * blockDim.x) {
                     const int s = e >> 9, l = (e >> 3) & 63, j = e & 7;
                     const int k = 32 * it + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
-                    const float w = src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + k];
+                    const float w = wscale * src.W[mat][(32 * nt + (l & 31)) * Kdim[mat] + k];
                     const int idx = ((tile * 2 + s) * 64 + l) * 8 + j;
                     if ((f16_mats >> mat) & 1) {                // this matrix as fp16 halves (the mixed modes read the high ones)
                         const _Float16 hh = (_Float16)w, hl = (_Float16)(w - (float)hh);
@@ -202,14 +203,10 @@ __device__ __forceinline__ f32x16 mm_w_h(const WFrag& w, const f32x16& in, f32x1
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // No clamp is needed past the fitted range: the polynomial keeps falling (its leading coefficient is negative), 2^q underflows
-// to zero and the term stays below 6e-8 for every t >= 5.6.  (Writing the last step as plain FMAs with |v| and the negation
-// as operand modifiers measured slower: the compiler materialises -|v| and canonicalises the maximum, 25 us instead of 18.)
-// max(v, 0) as exactly one instruction (the median of v, 0 and 3e38; with +inf the compiler folds it back into the two-instruction maximum): the builtin maximum first canonicalises its operand with
-// a second v_max_f32 (quieting of signalling NaNs), one more vector instruction per element of the hidden layer.  Not inline
-// assembly: the compiler does not insert the wait states between a matrix instruction's write and a vector read of the same
-// register for an instruction it cannot see.
-__device__ __forceinline__ float max0(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.0e38f); }
-
+// to zero and the term stays below 6e-8 for every t >= 5.6.
+// Both functions return TWICE the GELU, v + |v| (1 - 2 Phi(-|v|)) (max(v, 0) = (v + |v|) / 2): two packed instructions per pair
+// after the exponential instead of three; the weight image holds W2 / 2 (build_image_kernel; exact, a power of two).  For v < 0 the
+// two terms cancel to -2 |v| Phi(-|v|) with an absolute error of at most half an ulp of |v|.
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per call: the polynomial runs on packed fp32 FMAs
     const f32x2 t = __builtin_elementwise_abs(v);
     f32x2 q = t * -4.72791765e-04f + 7.08039424e-03f;
@@ -218,7 +215,7 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per cal
     q = t * q + -1.15078008e+00f;
     q = t * q + -1.00003892e+00f;
     const f32x2 e = {exp2_fast(q.x), exp2_fast(q.y)};
-    return f32x2{max0(v.x), max0(v.y)} - t * e;
+    return v + t * (1.0f - 2.0f * e);
 }
 
 // the same function on one value with plain (unpacked) FMAs: measurement aid for the packed form
@@ -229,7 +226,7 @@ __device__ __forceinline__ float gelu_erf1(float v) {
     q = fmaf(t, q, -4.60007281e-01f);
     q = fmaf(t, q, -1.15078008e+00f);
     q = fmaf(t, q, -1.00003892e+00f);
-    return fmaf(-av, exp2_fast(q), max0(v));
+    return fmaf(t, fmaf(-2.0f, exp2_fast(q), 1.0f), v);
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -280,6 +277,13 @@ constexpr int PACK_VECS = 13;   // float4 per lane per 32-row tile: exactly the 
 //     out = o/l + g (v - o/l),   g = 1 / (1 + 2^(c - s)),
 // which needs five floats instead of six and one exponential instead of two, and cannot overflow to NaN
 // (2^(c - s) = inf gives g = 0).
+// x0 is packed with the bias of the attention out-projection already added (vecs[0 .. 31]): the row kernel starts the
+// out-projection's accumulators from it, and the residual and bias additions cost it no instruction.
+__device__ __forceinline__ float4 x0_plus_bias(const EncRowsArgs& a, int64_t row, int f) {
+    const float4 x = *reinterpret_cast<const float4*>(a.x0 + row * D + f), b = *reinterpret_cast<const float4*>(a.vecs + f);
+    return make_float4(x.x + b.x, x.y + b.y, x.z + b.z, x.w + b.w);
+}
+
 __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, float4* __restrict__ packed, int64_t n_tiles) {
     // one thread per (tile, lane): the 13 vectors that lane will load
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const EncRowsArgs a, flo
     float4* dst = packed + tile * (PACK_VECS * 64) + lane;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        dst[64 * g] = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * g);
+        dst[64 * g] = x0_plus_bias(a, row, 4 * h + 8 * g);
         dst[64 * (4 + g)] = *reinterpret_cast<const float4*>(a.q + row * a.ldq + 4 * h + 8 * g);
     }
     const float4* sp = reinterpret_cast<const float4*>(a.state + row * (NH * 6) + h * 24);      // 96 bytes: 4 x {m, l, o[4]}
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void pack_gates_kernel(const EncRowsArgs a, fl
 #pragma unroll
             for (int k = 0; k < 4; ++k) oh[4 * g + k] = f16_sat(st[6 * g + 2 + k] * inv);
             if (live) {
-                dst[64 * g] = *reinterpret_cast<const float4*>(a.x0 + row * D + 4 * h + 8 * g);
+                dst[64 * g] = x0_plus_bias(a, row, 4 * h + 8 * g);
                 if constexpr (!HALF) dst[64 * (4 + g)] = make_float4(st[6 * g + 2] * inv, st[6 * g + 3] * inv, st[6 * g + 4] * inv, st[6 * g + 5] * inv);
             }
         }
@@ -537,7 +541,8 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             for (int g = 0; g < 4; ++g) {
                 const float4 t = *reinterpret_cast<const float4*>(ap + 8 * g + 4 * h);
                 att[4 * g] = t.x; att[4 * g + 1] = t.y; att[4 * g + 2] = t.z; att[4 * g + 3] = t.w;
-                in.x[g] = *reinterpret_cast<const float4*>(a.x0_time + 8 * g + 4 * h);
+                const float4 xt = *reinterpret_cast<const float4*>(a.x0_time + 8 * g + 4 * h), bt = *reinterpret_cast<const float4*>(bo + 8 * g + 4 * h);
+                in.x[g] = make_float4(xt.x + bt.x, xt.y + bt.y, xt.z + bt.z, xt.w + bt.w);
             }
             // These loads run in 1 tile of 25.  Their wait must sit INSIDE this branch: placed at the first use after the
             // branch it would run on every tile and, with nothing loaded, wait for the previous tile's stores instead.
@@ -586,17 +591,22 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
                 att[4 * g + 3] = fmaf(gate, vv.w - o3, o3);
             }
         }
-        // ---- y1 = x0 + Wo att + bo
-        f32x16 y1 = (MIX & 2) ? mm_h(img, tile_base(0), att, zero16(), lane) : mm<PREC>(img, tile_base(0), att, zero16(), lane);
+        // ---- y1 = (x0 + bo) + Wo att: the packed row is the accumulators' initial value
+        f32x16 y1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 x = in.x[g];
-            const float4 b = *reinterpret_cast<const float4*>(bo + 8 * g + 4 * h);
-            y1[4 * g + 0] += x.x + b.x; y1[4 * g + 1] += x.y + b.y; y1[4 * g + 2] += x.z + b.z; y1[4 * g + 3] += x.w + b.w;
+            y1[4 * g + 0] = x.x; y1[4 * g + 1] = x.y; y1[4 * g + 2] = x.z; y1[4 * g + 3] = x.w;
         }
+        y1 = (MIX & 2) ? mm_h(img, tile_base(0), att, y1, lane) : mm<PREC>(img, tile_base(0), att, y1, lane);
         // ---- y2 = y1 + W2 gelu(W1 LN(y1) + b1) + b2, one 32-wide slice of the hidden layer at a time
         const f32x16 hn = layer_norm32(y1, g2, be2, h);
-        f32x16 acc2 = zero16();
+        f32x16 acc2;                                    // starts from the bias of the second FFN layer
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(b2 + 8 * g + 4 * h);
+            acc2[4 * g + 0] = b.x; acc2[4 * g + 1] = b.y; acc2[4 * g + 2] = b.z; acc2[4 * g + 3] = b.w;
+        }
         if constexpr (PREC == PREC_BF16X3) {
             WFrag w1 = load_w(img, tile_base(1), lane);
 #pragma unroll 1
@@ -639,11 +649,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         }
         f32x16 y2;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b = *reinterpret_cast<const float4*>(b2 + 8 * g + 4 * h);
-            y2[4 * g + 0] = y1[4 * g + 0] + acc2[4 * g + 0] + b.x; y2[4 * g + 1] = y1[4 * g + 1] + acc2[4 * g + 1] + b.y;
-            y2[4 * g + 2] = y1[4 * g + 2] + acc2[4 * g + 2] + b.z; y2[4 * g + 3] = y1[4 * g + 3] + acc2[4 * g + 3] + b.w;
-        }
+        for (int q = 0; q < 16; ++q) y2[q] = y1[q] + acc2[q];
         // ---- next tile's inputs (clamped: a wave's last iteration re-reads the last tile and drops it)
         asm volatile("" ::: "memory");
         fetch_row((ABL & 8) ? min((int64_t)wave_global, last_tile) : min((tile0 >> 5) + n_waves, last_tile));
