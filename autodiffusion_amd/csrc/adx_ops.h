@@ -208,6 +208,7 @@ struct AttnGArgs {
     int B = 0, L = 0, n_keep = 0;
     float scale = 1.f;
     int prio = 0;                                    // as EncRowsArgs::prio
+    float lazy = 8.f;                                // a column's softmax reference moves only when a score exceeds it by more than this (log2 units; 0: on every new maximum)
 };
 bool attention_g_ok(int n_keep);
 hipError_t attention_g(const AttnGArgs& a, int prec, hipStream_t stream, int mix = 0);     // mix (split-bf16 mode): 1 weighted sums in fp16, 3 scores and V too, 7 the rows arrive as fp16

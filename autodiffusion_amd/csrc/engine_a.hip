@@ -529,6 +529,7 @@ struct EngineA final : adx_engine {
             g.O = par ? ATTb : ATT; g.ldo = d; g.o_batch_stride = (int64_t)L * d;
             g.B = B; g.L = L; g.n_keep = T + 1; g.scale = 1.0f / sqrtf((float)(d / H));
             g.prio = step_prio();
+            if (const char* lz = getenv("ADX_ATTN_LAZY")) g.lazy = (float)atof(lz);      // tuning knob, read per call
             ADX_HIP(attention_g(g, cfg.precision, s, ((mix >> 1) & 3) | (half_io() ? 4 : 0)));
         } else {
             ADX_HIP(attention_few_queries(fused_attn_args(B, par), s));
@@ -728,6 +729,7 @@ struct EngineA final : adx_engine {
             if (ns) overlap_streams = atoi(ns);
             const char* mb = getenv("ADX_OVERLAP_MAX_B");                // tuning knob: largest batch whose tail runs on the second stream
             if (mb) overlap_max_b = atoi(mb);
+            else if (f16_single) overlap_max_b = 3072;                   // fp16 engine, trajectories/s with / without: 2048 scenarios 21.1 k / 20.5 k, 4096: 21.0 k / 22.0 k
         }
         return ADX_OK;
     }

@@ -882,15 +882,23 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
 #pragma unroll
                 for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, sc[reg]);
                 mx = xor32_max(mx);
-                const float mn = fmaxf(m[nb], mx);
-                const float fac = exp2_fast(m[nb] - mn);
-                m[nb] = mn;
+                // The reference value of a column moves only when a score exceeds it by more than a.lazy (log2 units): the weights
+                // then stay below 2^lazy, well inside fp16 and bf16, and the partial sums are rescaled in the first group and
+                // hardly ever after it (wave-uniform branch) instead of in every group.  Depends on the item's own rows only.
+                const bool up = mx > m[nb] + a.lazy;
+                if (__any(up)) {
+                    const float mn = up ? mx : m[nb];
+                    const float fac = exp2_fast(m[nb] - mn);
+                    m[nb] = mn;
+                    l[nb] *= fac;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) o[nb][reg] *= fac;
+                }
+                const float mn = m[nb];
                 float sum = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) { sc[reg] = (ABL & 1) ? sc[reg] - mn : exp2_fast(sc[reg] - mn); sum += sc[reg]; }
-                l[nb] = fmaf(l[nb], fac, sum);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) o[nb][reg] *= fac;
+                l[nb] += sum;
                 if constexpr (MIX != 0) return sc;
                 else if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
                 else return to_opnd<PREC>(sc);
