@@ -238,25 +238,23 @@ __device__ __forceinline__ f32x16 zero16() {
 
 // LayerNorm over the 32 features of each row: 16 in this lane, 16 in lane ^ 32
 __device__ __forceinline__ f32x16 layer_norm32(const f32x16& y, const float* gamma, const float* beta, int h) {
-    float s = 0.f;
+    // written on pairs: the sums, the centring and the affine map as packed instructions (41 instead of ~60 per call)
+    f32x2 s2 = {y[0], y[1]};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += y[i];
-    s = xor32_add(s);
-    const float mean = s * (1.0f / 32.0f);
-    float q = 0.f;
+    for (int i = 2; i < 16; i += 2) s2 += f32x2{y[i], y[i + 1]};
+    const float mean = xor32_add(s2.x + s2.y) * (1.0f / 32.0f);
+    f32x2 d[8], q2 = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const float t = y[i] - mean; q = fmaf(t, t, q); }
-    q = xor32_add(q);
-    const float rstd = rsqrt_fast(fmaf(q, 1.0f / 32.0f, 1e-5f));
+    for (int i = 0; i < 8; ++i) { d[i] = f32x2{y[2 * i], y[2 * i + 1]} - f32x2{mean, mean}; q2 += d[i] * d[i]; }
+    const float rstd = rsqrt_fast(fmaf(xor32_add(q2.x + q2.y), 1.0f / 32.0f, 1e-5f));
     f32x16 o;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const float4 ga = *reinterpret_cast<const float4*>(gamma + 8 * g + 4 * h);
         const float4 be = *reinterpret_cast<const float4*>(beta + 8 * g + 4 * h);
-        o[4 * g + 0] = fmaf((y[4 * g + 0] - mean) * rstd, ga.x, be.x);
-        o[4 * g + 1] = fmaf((y[4 * g + 1] - mean) * rstd, ga.y, be.y);
-        o[4 * g + 2] = fmaf((y[4 * g + 2] - mean) * rstd, ga.z, be.z);
-        o[4 * g + 3] = fmaf((y[4 * g + 3] - mean) * rstd, ga.w, be.w);
+        const f32x2 a = d[2 * g] * f32x2{rstd, rstd} * f32x2{ga.x, ga.y} + f32x2{be.x, be.y};
+        const f32x2 b = d[2 * g + 1] * f32x2{rstd, rstd} * f32x2{ga.z, ga.w} + f32x2{be.z, be.w};
+        o[4 * g + 0] = a.x; o[4 * g + 1] = a.y; o[4 * g + 2] = b.x; o[4 * g + 3] = b.y;
     }
     return o;
 }
@@ -896,8 +894,20 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
                 }
                 const float mn = m[nb];
                 float sum = 0.f;
+                if constexpr (MIX != 0) {                       // pairs: the subtraction and the sum as packed instructions
+                    f32x2 sum2 = {0.f, 0.f};                    // (the split-bf16 instance has no registers to spare for this form)
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) { sc[reg] = (ABL & 1) ? sc[reg] - mn : exp2_fast(sc[reg] - mn); sum += sc[reg]; }
+                    for (int reg = 0; reg < 16; reg += 2) {
+                        f32x2 dd = f32x2{sc[reg], sc[reg + 1]} - f32x2{mn, mn};
+                        dd = f32x2{exp2_fast(dd.x), exp2_fast(dd.y)};
+                        sc[reg] = dd.x; sc[reg + 1] = dd.y;
+                        sum2 += dd;
+                    }
+                    sum = sum2.x + sum2.y;
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) { sc[reg] = (ABL & 1) ? sc[reg] - mn : exp2_fast(sc[reg] - mn); sum += sc[reg]; }
+                }
                 l[nb] += sum;
                 if constexpr (MIX != 0) return sc;
                 else if constexpr ((ABL & 8) != 0) { Opnd<PREC> r = gop; r.h[0][0] = (__bf16)sum; return r; }
