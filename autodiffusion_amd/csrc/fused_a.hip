@@ -207,16 +207,19 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // Both functions return TWICE the GELU, v + |v| (1 - 2 Phi(-|v|)) (max(v, 0) = (v + |v|) / 2): two packed instructions per pair
 // after the exponential instead of three; the weight image holds W2 / 2 (build_image_kernel; exact, a power of two).  For v < 0 the
 // two terms cancel to -2 |v| Phi(-|v|) with an absolute error of at most half an ulp of |v|.
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {      // two values per call: the polynomial runs on packed fp32 FMAs
-    const f32x2 t = __builtin_elementwise_abs(v);
-    f32x2 q = t * -4.72791765e-04f + 7.08039424e-03f;
-    q = t * q + -5.18154655e-02f;
-    q = t * q + -4.60007281e-01f;
-    q = t * q + -1.15078008e+00f;
-    q = t * q + -1.00003892e+00f;
-    const f32x2 e = {exp2_fast(q.x), exp2_fast(q.y)};
-    return v + t * (1.0f - 2.0f * e);
+// Plain FMAs with |v| as a source modifier of each: measured on this chip (profiles/micro/valu_issue.hip, four waves per SIMD)
+// a packed fp32 FMA issues in 1.9 x the time of a plain one, so packing buys 5 % and costs the instruction that forms |v|.
+__device__ __forceinline__ float gelu2_(float v) {
+    float q = fmaf(fabsf(v), -4.72791765e-04f, 7.08039424e-03f);
+    q = fmaf(fabsf(v), q, -5.18154655e-02f);
+    q = fmaf(fabsf(v), q, -4.60007281e-01f);
+    q = fmaf(fabsf(v), q, -1.15078008e+00f);
+    q = fmaf(fabsf(v), q, -1.00003892e+00f);
+    float r = fmaf(fabsf(v), fmaf(-2.0f, exp2_fast(q), 1.0f), v);
+    asm("" : "+v"(r));          // opaque to the vectoriser, which would pair the last two steps into packed FMAs and form |v| for them
+    return r;
 }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) { return f32x2{gelu2_(v.x), gelu2_(v.y)}; }
 
 // the same function on one value with plain (unpacked) FMAs: measurement aid for the packed form
 __device__ __forceinline__ float gelu_erf1(float v) {
@@ -504,7 +507,15 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         } else
         for (int i = threadIdx.x; i < IMG_F32_FLOATS / 4; i += NT) dst[i] = src[i];
         for (int i = threadIdx.x; i < VEC_FLOATS; i += NT) vec[i] = a.vecs[i];
-        if (threadIdx.x < 64) vec[VEC_FLOATS + threadIdx.x] = a.key0[threadIdx.x] * (threadIdx.x < 32 ? sc : 1.0f);
+        if (threadIdx.x < 64 && (!HIO || threadIdx.x >= 32)) vec[VEC_FLOATS + threadIdx.x] = a.key0[threadIdx.x] * (threadIdx.x < 32 ? sc : 1.0f);
+        if constexpr (HIO) {
+            // half-width form: the gates come from the table, so the key's place holds the time token's value as fp16 in the order a lane's
+            // operand registers want it: [half h][k-step s][j] <-> feature 8 (2 s + (j >> 2)) + 4 h + (j & 3)
+            if (threadIdx.x < 32) {
+                const int hh = threadIdx.x >> 4, ss = (threadIdx.x >> 3) & 1, j = threadIdx.x & 7;
+                reinterpret_cast<_Float16*>(vec + VEC_FLOATS)[threadIdx.x] = (_Float16)a.key0[32 + 8 * (2 * ss + (j >> 2)) + 4 * hh + (j & 3)];
+            }
+        }
     }
     __syncthreads();
     const float *bo = vec, *g2 = vec + 32, *be2 = vec + 64, *b2 = vec + 96, *g1 = vec + 128, *be1 = vec + 160, *b1 = vec + 192,
@@ -533,6 +544,7 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
         const int r = (int)((unsigned)row % (unsigned)a.L);      // B * L < 2^31 is checked by the launcher
         // ---- attention output of layer 0 in accumulator layout: register 4g+i <-> feature 8g + 4h + i
         f32x16 att;
+        f16x8 ah[2] = {};                                       // half-width form: the same values as the fp16 operand of the out-projection
         if (r == 0) {                                           // the time token: inputs change every step
             const float* ap = a.att0 + (int64_t)((unsigned)row / (unsigned)a.L) * D;
 #pragma unroll
@@ -547,20 +559,20 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             typedef __attribute__((ext_vector_type(4))) float v4;
             v4* xp = reinterpret_cast<v4*>(in.x);
             asm volatile("" : "+v"(att), "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xp[3]));
+            if constexpr (HIO) { ah[0] = to_f16x8(att, 0); ah[1] = to_f16x8(att, 1); }
         } else if constexpr (HIO) {
+            // o (1 - gate) + gate v0 in packed fp16 arithmetic, straight into the operand registers (o arrives as fp16 and the product rounds
+            // its operand to fp16 anyway; the gates are ~1 / 800, so rounding v0 - o moves the result by far less than that rounding):
+            // 16 packed instructions instead of 56 conversions, subtractions and multiply-adds
             typedef __attribute__((ext_vector_type(4))) _Float16 h4;
             const h4 gt = __builtin_bit_cast(h4, in.gate);
-            const f16x8 ov[2] = {__builtin_bit_cast(f16x8, in.o[0]), __builtin_bit_cast(f16x8, in.o[1])};
+            const f16x8* v0h = reinterpret_cast<const f16x8*>(k0s) + 2 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 vv = *reinterpret_cast<const float4*>(v0s + 8 * g + 4 * h);
-                const float gg = (float)gt[g];
-                const float o0 = (float)ov[g >> 1][4 * (g & 1)], o1 = (float)ov[g >> 1][4 * (g & 1) + 1], o2 = (float)ov[g >> 1][4 * (g & 1) + 2],
-                            o3 = (float)ov[g >> 1][4 * (g & 1) + 3];
-                att[4 * g + 0] = fmaf(gg, vv.x - o0, o0);
-                att[4 * g + 1] = fmaf(gg, vv.y - o1, o1);
-                att[4 * g + 2] = fmaf(gg, vv.z - o2, o2);
-                att[4 * g + 3] = fmaf(gg, vv.w - o3, o3);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const f16x8 ov = __builtin_bit_cast(f16x8, in.o[s2]);
+                const _Float16 ga = gt[2 * s2], gb = gt[2 * s2 + 1], na = (_Float16)1 - ga, nb = (_Float16)1 - gb;
+                const f16x8 g8 = {ga, ga, ga, ga, gb, gb, gb, gb}, n8 = {na, na, na, na, nb, nb, nb, nb};
+                ah[s2] = ov * n8 + g8 * v0h[s2];
             }
         } else if constexpr (GATES) {
             const float gt[4] = {in.gate.x, in.gate.y, in.gate.z, in.gate.w};
@@ -596,6 +608,11 @@ __global__ __launch_bounds__(WAVES == 4 ? 512 : 256, WAVES) void enc_rows_kernel
             const float4 x = in.x[g];
             y1[4 * g + 0] = x.x; y1[4 * g + 1] = x.y; y1[4 * g + 2] = x.z; y1[4 * g + 3] = x.w;
         }
+        if constexpr (HIO) {
+            const unsigned short* wo = reinterpret_cast<const unsigned short*>(img) + (tile_base(0) * 2 * 64 + lane) * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) y1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(wo + s2 * 64 * 8), ah[s2], y1, 0, 0, 0);
+        } else
         y1 = (MIX & 2) ? mm_h(img, tile_base(0), att, y1, lane) : mm<PREC>(img, tile_base(0), att, y1, lane);
         // ---- y2 = y1 + W2 gelu(W1 LN(y1) + b1) + b2, one 32-wide slice of the hidden layer at a time
         const f32x16 hn = layer_norm32(y1, g2, be2, h);
