@@ -172,7 +172,9 @@ def roofline(da, B, step, precision="bf16x3"):
         line["issue"] = {"valu_insts": round(valu), "mfma_insts": round(mfma), "model_us": round(model_us, 1),
                          "frac": round(model_us / (t["enc_rows"] * 1e6), 4), "clock_ghz": CLOCK_GHZ, "simds": SIMDS,
                          "model": "(4 cycles x vector instructions + 32 cycles x matrix instructions) / (SIMDs x clock): the time the kernel's own "
-                                  "instruction stream needs at full issue rate; frac = model_us / launch_us",
+                                  "instruction stream needs at full issue rate; frac = model_us / launch_us.  A lower bound of the limit: every vector "
+                                  "instruction is priced at 4 cycles, while the kernel's exponentials (66 per 32-row tile and lane) issue in ~3.6x and its "
+                                  "packed fp32 instructions in ~1.9x that (profiles/r03_valu_issue.txt), and the chip holds ~2.0 GHz, not 2.4, under this load",
                          "source": f"{src} (SQ_INSTS_VALU, SQ_INSTS_MFMA per launch at B=1024, scaled by the row count; not collected in this run)"}
     return line
 
@@ -649,11 +651,13 @@ def main():
                                    + ", random init, synthetic nuPlan-shaped conditioning",
                        "batch_per_gpu": B, "global_batch": total, "denoiser_calls_per_step": (80 // FS) * N_SAMPLE,
                        "parallelism": f"dp{world}",
-                       "precision": {"bf16x3": "bf16 MFMA on split (hi+lo) operands, 3 MFMAs per product, f32 accumulate; trajectory path and scheduler f32",
+                       "precision": {"bf16x3": "bf16 MFMA on split (hi+lo) operands, 3 MFMAs per product, f32 accumulate; the fused tail (decoder, scheduler step) on split-fp16 "
+                                               "operands (fp16 hi + scaled lo, 3 MFMAs per product, ~2^-21 per product)",
                                      "bf16": "bf16 MFMA operands, f32 accumulate; trajectory path and scheduler f32",
                                      "f16": "split-bf16 engine whose two per-step kernels over all conditioning rows (encoder row pipeline, last encoder attention) "
-                                            "multiply operands rounded once to fp16: one f16 MFMA per product, f32 accumulate; per-chunk caches and the "
-                                            "memory-row maps of the tail split-bf16 (3 MFMAs per product); trajectory path and scheduler f32",
+                                            "multiply operands rounded once to fp16: one f16 MFMA per product, f32 accumulate; the fused tail (rest of the last encoder layer on "
+                                            "the visible rows, decoder, head) on split-fp16 operands (fp16 hi + scaled lo, 3 MFMAs per product, ~2^-21 per product); "
+                                            "per-chunk caches and the scheduler step f32",
                                      "fp32": "f32 MFMA"}[args.precision]},
         }
         if FS == 10:                                             # the fused kernels the roofline entry describes need T + 1 <= 16
@@ -672,8 +676,8 @@ def main():
             r3 = roofline(da, B, sample3, "bf16x3")
             line["bf16x3"] = {"value": round(B * 3 / dt3, 2), "unit": "trajectories/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "roofline_frac": r3["frac"],
                               "launch_us": r3["launch_us"], "stages_us": r3["stages_us"],
-                              "note": "precision bf16x3 (3 bf16 MFMAs per product everywhere): ADE against fp32 5e-4 m median / 1.4e-3 m worst over 1024 "
-                                      "scenarios; the headline precision: 1.1e-3 / 3.7e-3 m (gate 1e-2 m, profiles/ade_mixed.py)"}
+                              "note": "precision bf16x3 (3 bf16 MFMAs per product in the kernels over all conditioning rows): ADE against fp32 4.7e-4 m median / "
+                                      "1.2e-3 m worst over 1024 scenarios; the headline precision: 1.06e-3 / 3.7e-3 m (gate 1e-2 m, profiles/tail_forms.py)"}
             da = da_main
         line["dit_gemm"] = dit_gemm(dev)
         line["train_step"] = train_step(dev)
