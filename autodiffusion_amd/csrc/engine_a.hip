@@ -256,7 +256,9 @@ struct EngineA final : adx_engine {
         // rows split-bf16 + trajectory tokens fp32, "20" the most accurate of the reduced forms.
         tail_mem = tail_traj = tail_split ? 2 : 0;
         if (const char* tf = getenv("ADX_TAIL_FORMS")) {
-            if (tail_split && tf[0] >= '0' && tf[0] <= '2' && tf[1] >= '0' && tf[1] <= '2') { tail_mem = tf[0] - '0'; tail_traj = tf[1] - '0'; }
+            const int m = tf[0] - '0', t = tf[0] ? tf[1] - '0' : -1;
+            const bool supported = (m == 0 && t == 0) || (m == 1 && t == 0) || (m == 2 && t == 0) || (m == 2 && t == 2);      // the instances tail_mfma() has
+            if (tail_split && supported) { tail_mem = m; tail_traj = t; }
         }
         bool mem_side = true;              // blocks that act on memory rows
         auto block = [&](const std::string& w, int ldw, int row0, int col0) {
