@@ -805,7 +805,7 @@ constexpr float AG_NEG = -1.0e30f;
 // MIX (split-bf16 mode only), bits: 1 the weighted sums O^T += V^T P^T with V and P rounded once to fp16; 2 also the scores and V
 // from g, the folded queries and Wv rounded once to fp16; 4 (with 2) the LayerNorm rows arrive as fp16, as the half-width row kernel stores them
 template <int PREC, int ABL = 0, int MIX = 0>      // ABL: measurement aid (results are wrong except for 16): 1 no exponentials, 2 no weighted-sum products, 4 no score products, 8 no operand splits of the weights, 16 hand-placed instruction order
-__global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
+__device__ __forceinline__ void attn_g_body(const AttnGArgs& a, const float* img_f32, const unsigned short* img_bf) {
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     __shared__ float mrg[(6 + 48) * 64];
     __shared__ Opnd<PREC> qsh[3][64];
@@ -1047,6 +1047,19 @@ __global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const
     }
 }
 
+template <int PREC, int ABL = 0, int MIX = 0>
+__global__ __launch_bounds__(128, 2) void attn_g_kernel(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
+    attn_g_body<PREC, ABL, MIX>(a, img_f32, img_bf);
+}
+
+// The fp16 forms with a budget of 192 registers per lane (the form the fp16 engine runs, 7, keeps it: 191 without spilling; the compiler
+// exceeds it for the partial forms 1 and 3): two of its waves and one wave of the tail (120 registers), which runs beside them on the second
+// stream, then fit the 512 registers of a SIMD lane together (at 200 a SIMD holding a tail wave takes only one of these): +0.4 %, same bits.
+template <int MIX>
+__global__ __launch_bounds__(128, 2) __attribute__((amdgpu_num_vgpr(192))) void attn_g_kernel_h(const AttnGArgs a, const float* img_f32, const unsigned short* img_bf) {
+    attn_g_body<PREC_BF16X3, 0, MIX>(a, img_f32, img_bf);
+}
+
 }  // namespace
 
 size_t enc_rows_image_bytes() { return sizeof(float) * IMG_F32_FLOATS + sizeof(unsigned short) * IMG_BF_SHORTS; }
@@ -1170,10 +1183,10 @@ hipError_t attention_g(const AttnGArgs& a0, int prec, hipStream_t stream, int mi
     const unsigned short* img_bf = reinterpret_cast<const unsigned short*>(img_f32 + IMG_F32_FLOATS);
     if (mix) {
         if (prec != PREC_BF16X3) return hipErrorInvalidValue;
-        if ((mix & 6) == 6) hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 7>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        if ((mix & 6) == 6) hipLaunchKernelGGL((attn_g_kernel_h<7>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
         else if (mix & 4) return hipErrorInvalidValue;
-        else if (mix & 2) hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 3>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
-        else hipLaunchKernelGGL((attn_g_kernel<PREC_BF16X3, 0, 1>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        else if (mix & 2) hipLaunchKernelGGL((attn_g_kernel_h<3>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
+        else hipLaunchKernelGGL((attn_g_kernel_h<1>), dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
         return hipGetLastError();
     }
     if (prec == PREC_F32) hipLaunchKernelGGL(attn_g_kernel<PREC_F32>, dim3(a.B), dim3(128), 0, stream, a, img_f32, img_bf);
