@@ -284,6 +284,7 @@ struct TailMfmaArgs {
     // arithmetic form the blocks were packed in (tail_mfma_pack_block(..., split)): `split` for the maps on memory rows, `traj` for
     // the maps on trajectory tokens.  0 fp32, 1 split-bf16 (memory rows only), 2 split-fp16; supported pairs: (0,0) (1,0) (2,0) (2,2)
     int split = 0, traj = 0;
+    int prio = 0;                     // wave priority (s_setprio 0..3) against the kernels that run beside the tail on other streams
 };
 struct TailMfmaVecLayout {
     int e_bo, e_ln2_g, e_ln2_b, e_b1, e_b2, din_b, pos, layer0, layer_size;

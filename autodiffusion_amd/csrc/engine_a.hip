@@ -71,14 +71,17 @@ struct EngineA final : adx_engine {
     // encoder side does not depend on x at all: the tail of step k runs on a second stream under the encoder kernels of
     // step k + 1.  Its inputs (the last encoder layer's attention output and residual rows) are double-buffered by step parity.
     float *ATTb = nullptr;                    // second buffer of ATT (XB is the second buffer of XA)
+    float *XC = nullptr, *XD = nullptr, *ATTc = nullptr, *ATTd = nullptr;      // third and fourth buffers of both (overlap depth 3 / 4)
+    static constexpr int MAX_DEPTH = 4;
+    int depth = 2;                            // steps the encoder kernels may run ahead of the tail (sets of per-step buffers in rotation; ADX_OVERLAP_DEPTH)
     float *GT = nullptr;                      // [n_steps][tiles][64] float4: the fold gates of every step of the chunk (gate-table form of the row kernel)
     bool gate_table = false;
     int mix = 0;               // products with both operands rounded once to fp16 (set at finalize): 1 | 16 | 32 the row kernel's second FFN product, out-projection and
                                // first FFN product, 2 the weighted sums of the last encoder attention, 4 its scores and V (with 2), 8 (with all of them and the gate table) fp16 o / l,
                                // gates and LayerNorm rows in memory
-    float *Q1C = nullptr;                     // [2][B][T + 1][d] layer-1 queries of the visible rows, by step parity (LayerNorm-row attention)
+    float *Q1C = nullptr;                     // [depth][B][T + 1][d] layer-1 queries of the visible rows, by buffer set (LayerNorm-row attention)
     hipStream_t side_stream = nullptr, att_stream = nullptr;
-    hipEvent_t ev_enc[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_att[2] = {nullptr, nullptr};
+    hipEvent_t ev_enc[MAX_DEPTH] = {}, ev_tail[MAX_DEPTH] = {}, ev_att[MAX_DEPTH] = {};
     int overlap_streams = 2;                  // 3: the last encoder attention of step k runs on a stream of its own, beside the row kernel of step k + 1
     bool overlap_ok = false;
     int overlap_max_b = 1536;
@@ -93,7 +96,7 @@ struct EngineA final : adx_engine {
         if (tailm_vecs) (void)hipFree(tailm_vecs);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         if (att_stream) (void)hipStreamDestroy(att_stream);
-        for (int i = 0; i < 2; ++i) if (ev_att[i]) (void)hipEventDestroy(ev_att[i]);
+        for (hipEvent_t e : ev_att) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_enc) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_tail) if (e) (void)hipEventDestroy(e);
     }
@@ -120,6 +123,7 @@ struct EngineA final : adx_engine {
         const char* no_mfma = getenv("ADX_TAIL_VALU");       // tuning knob: force the VALU form of the tail
         tail_mfma_ok = fused && T + 1 <= 96 && Cin == 4 && Cout == 4 && n_dec <= 4 && !(no_mfma && no_mfma[0] == '1');
         {
+            if (const char* dp = getenv("ADX_OVERLAP_DEPTH")) depth = std::min((int)MAX_DEPTH, std::max(2, atoi(dp)));      // tuning knob: sets of per-step buffers
             const char* f32_tail = getenv("ADX_TAIL_F32");       // tuning / fallback switch: fp32 MFMAs in every precision mode
             tail_split = cfg.precision != ADX_PREC_F32 && !(f32_tail && f32_tail[0] == '1');
         }
@@ -176,8 +180,8 @@ struct EngineA final : adx_engine {
             take(&PK, enc_rows_packed_bytes(B, L) / sizeof(float));
             take(&ATT0, (size_t)B * std::max<size_t>(steps.size(), 1) * d);
             if (split_cache) take(&STM, BL * H * 6);
-            take(&KV1, std::max<int64_t>(BL * 2 * d, 2 * (int64_t)(enc_rows_g_bytes(B, L) / sizeof(float))));      // K | V rows, or two parities of LayerNorm rows
-            take(&Q1C, 2 * (int64_t)B * (T + 1) * d);
+            take(&KV1, std::max<int64_t>(BL * 2 * d, depth * (int64_t)(enc_rows_g_bytes(B, L) / sizeof(float))));      // K | V rows, or the sets of LayerNorm rows
+            take(&Q1C, depth * (int64_t)B * (T + 1) * d);
             {
                 // the gate table costs 32 B per row and step: used while it stays under a budget (long DDPM schedules at large
                 // batches fall back to evaluating the gates inside the row kernel)
@@ -188,6 +192,8 @@ struct EngineA final : adx_engine {
                 if (gate_table) take(&GT, (int64_t)(need / sizeof(float)));
             }
             take(&ATTb, BL * d);
+            if (depth >= 3) { take(&XC, BL * d); take(&ATTc, BL * d); }
+            if (depth >= 4) { take(&XD, BL * d); take(&ATTd, BL * d); }
         }
         *bytes = off;
         return ADX_OK;
@@ -314,18 +320,21 @@ struct EngineA final : adx_engine {
         return ADX_OK;
     }
 
+    float* x1_buf(int par) const { return par == 0 ? XA : par == 1 ? XB : par == 2 ? XC : XD; }
+    float* att_buf(int par) const { return par == 0 ? ATT : par == 1 ? ATTb : par == 2 ? ATTc : ATTd; }
+
     // Rest of the last encoder layer + decoder + head + scheduler update, one launch.
     int launch_tail(int B, const float* x, const float* z, const StepCoef* coef, float* x_next, float* out, hipStream_t s, int par = 0) {
         if (tail_mfma_ok) {
             TailMfmaArgs t;
-            t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = par ? ATTb : ATT; t.x1 = par ? XB : XA; t.x = x; t.z = z; t.coef = coef;
-            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_mem; t.traj = tail_traj;
+            t.image = tailm_image; t.vecs = tailm_vecs; t.att1 = att_buf(par); t.x1 = x1_buf(par); t.x = x; t.z = z; t.coef = coef;
+            t.x_next = x_next; t.model_out = out; t.B = B; t.L = L; t.T = T; t.n_dec = n_dec; t.split = tail_mem; t.traj = tail_traj; t.prio = tail_prio(B);
             t.pos = P("pos_emb");
             ADX_HIP(tail_mfma(t, s));
             return ADX_OK;
         }
         TailArgs t = tail_tpl;
-        t.w = tail_w; t.att1 = par ? ATTb : ATT; t.x1 = par ? XB : XA; t.x = x; t.z = z; t.coef = coef;
+        t.w = tail_w; t.att1 = att_buf(par); t.x1 = x1_buf(par); t.x = x; t.z = z; t.coef = coef;
         t.x_next = x_next; t.model_out = out;
         t.B = B; t.L = L; t.T = T; t.C = Cin; t.n_dec = n_dec;
         ADX_HIP(tail_a(t, s));
@@ -458,10 +467,15 @@ struct EngineA final : adx_engine {
 
     float4* g_rows(int B, int par) const { return reinterpret_cast<float4*>(KV1) + (int64_t)par * (int64_t)(enc_rows_g_bytes(B, L) / sizeof(float4)); }
 
-    // wave priority of the two kernels of a step that walk all rows (tuning knob ADX_A_PRIO, read per call)
-    // default: 3 for the fp16 engines -- their waves then issue ahead of the tail's, which has slack: 58.9 -> 57.5 ms per generate at 1024
-    // scenarios, same bits -- and 0 for the others (the split-bf16 kernels leave the tail no slack: 79.6 -> 82.8 ms with 3)
-    int step_prio() const { const char* e = getenv("ADX_A_PRIO"); return e ? atoi(e) : (mix ? 3 : 0); }
+    // Wave priorities (s_setprio) of the two kernels of a step that walk all rows (ADX_A_PRIO) and of the tail beside them on the second
+    // stream (ADX_TAIL_PRIO; tuning knobs, read per call).  Which side should issue first depends on which one closes the step's critical
+    // cycle tail(k - 2) -> row kernel(k) -> attention(k) -> tail(k) (profiles/step_gaps.py).  fp16 engine, ms per generate with the row
+    // kernels / the tail favoured: 256 scenarios 27.9 / 23.7, 512: 38.1 / 35.1, 1024: 52.6 / 50.3, 2048: 98.0 / 100.0 -- up to the batch
+    // at which the row kernels alone fill the chip the tail's waves go first, above it the row kernels'.  Split-bf16 engine (its row
+    // kernels are a third longer and leave the tail no slack): no priorities (1024 scenarios: 77.7, tail favoured 79.9, rows favoured 82.8).
+    bool tail_first(int B) const { return mix != 0 && B <= 1536; }
+    int step_prio(int B) const { const char* e = getenv("ADX_A_PRIO"); return e ? atoi(e) : (mix && !tail_first(B) ? 3 : 0); }
+    int tail_prio(int B) const { const char* e = getenv("ADX_TAIL_PRIO"); return e ? atoi(e) : (tail_first(B) ? 3 : 0); }
     bool half_io() const { return (mix & 8) && (mix & 0x31) == 0x31 && (mix & 6) == 6 && gate_table && attn_g; }
     int rows_mix() const { return ((mix & 0x31) == 0x31 ? 7 : 0) | (half_io() ? 8 : 0); }
 
@@ -472,14 +486,14 @@ struct EngineA final : adx_engine {
         r.x0_time = tx0 + (int64_t)step * d;
         r.key0 = tqkv0 + (int64_t)step * 3 * d + d;
         r.image = rows_image; r.vecs = rows_vecs;
-        r.kv = KV1; r.ldkv = 2 * d; r.x1 = par ? XB : XA; r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
+        r.kv = KV1; r.ldkv = 2 * d; r.x1 = x1_buf(par); r.q1 = QKV; r.ldq1 = 3 * d;     // layer-1 K | V compact: both kernels stream whole rows
         if (attn_g) {       // the LayerNorm rows (128 B per row) take the place of K | V (256 B); they and the queries are double-buffered by step parity
             r.gpk = g_rows(B, par);
             if (gate_table) r.gates = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(GT) + (int64_t)step * (int64_t)(enc_rows_gates_bytes(B, L, 1) / (half_io() ? 2 : 1)));
             r.q1 = Q1C + (int64_t)par * B * (T + 1) * d; r.ldq1 = d; r.q1_item_stride = (int64_t)(T + 1) * d;
         }
         r.B = B; r.L = L; r.n_keep = T + 1; r.scale = 1.0f / sqrtf((float)(d / H));
-        r.prio = step_prio();
+        r.prio = step_prio(B);
         return r;
     }
 
@@ -528,9 +542,9 @@ struct EngineA final : adx_engine {
             g.gpk = g_rows(B, par); g.image = rows_image; g.vecs = rows_vecs;
             g.wk = P("encoder.layers.1.self_attn.in_proj_weight") + (int64_t)d * d;
             g.q1 = Q1C + (int64_t)par * B * (T + 1) * d; g.ldq1 = d; g.q1_item_stride = (int64_t)(T + 1) * d;
-            g.O = par ? ATTb : ATT; g.ldo = d; g.o_batch_stride = (int64_t)L * d;
+            g.O = att_buf(par); g.ldo = d; g.o_batch_stride = (int64_t)L * d;
             g.B = B; g.L = L; g.n_keep = T + 1; g.scale = 1.0f / sqrtf((float)(d / H));
-            g.prio = step_prio();
+            g.prio = step_prio(B);
             if (const char* lz = getenv("ADX_ATTN_LAZY")) g.lazy = (float)atof(lz);      // tuning knob, read per call
             ADX_HIP(attention_g(g, cfg.precision, s, ((mix >> 1) & 3) | (half_io() ? 4 : 0)));
         } else {
@@ -541,7 +555,7 @@ struct EngineA final : adx_engine {
 
     AttentionArgs fused_attn_args(int B, int par = 0) const {
         AttentionArgs at = enc_attn_args(B, T + 1);
-        if (par) at.O = ATTb;
+        if (par) at.O = att_buf(par);
         at.K = KV1; at.V = KV1 + d; at.ldk = at.ldv = 2 * d; at.k_batch_stride = at.v_batch_stride = (int64_t)L * 2 * d;
         return at;
     }
@@ -719,14 +733,14 @@ struct EngineA final : adx_engine {
         ADX_TRY(reserve(B));
         if (fused && (tail_ok || tail_mfma_ok) && !side_stream) {        // never created inside a capture
             ADX_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MAX_DEPTH; ++i) {
                 ADX_HIP(hipEventCreateWithFlags(&ev_enc[i], hipEventDisableTiming));
                 ADX_HIP(hipEventCreateWithFlags(&ev_tail[i], hipEventDisableTiming));
             }
             const char* no = getenv("ADX_NO_OVERLAP");                   // fallback switch: every kernel of a step on one stream
             overlap_ok = !(no && no[0] == '1');
             ADX_HIP(hipStreamCreateWithFlags(&att_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 2; ++i) ADX_HIP(hipEventCreateWithFlags(&ev_att[i], hipEventDisableTiming));
+            for (int i = 0; i < MAX_DEPTH; ++i) ADX_HIP(hipEventCreateWithFlags(&ev_att[i], hipEventDisableTiming));
             const char* ns = getenv("ADX_OVERLAP_STREAMS");               // tuning knob: 2 = tail on a second stream, 3 = attention on a third
             if (ns) overlap_streams = atoi(ns);
             const char* mb = getenv("ADX_OVERLAP_MAX_B");                // tuning knob: largest batch whose tail runs on the second stream
@@ -774,19 +788,22 @@ struct EngineA final : adx_engine {
         // under the encoder kernels; above, both fill the chip and only disturb each other.
         const bool overlap = cached && fused && (tail_ok || tail_mfma_ok) && overlap_ok && !profiling && side_stream && B <= overlap_max_b;
         if (overlap) {
-            // stream s: encoder rows + last-layer attention of step k (buffers of parity k & 1);
+            // stream s: encoder rows + last-layer attention of step k (buffer set k % depth);
             // side stream: tail of step k, after its encoder kernels and (stream order) after the tail of step k - 1.
-            // The encoder kernels of step k reuse the buffers the tail of step k - 2 read: they wait for it.
+            // The encoder kernels of step k reuse the buffers the tail of step k - depth read: they wait for it.  With two sets that wait
+            // closes the step's critical cycle (tail(k - 2) -> row kernel(k) -> attention(k) -> tail(k), with a dependency latency of
+            // 9-16 us on each edge: profiles/step_gaps.py).  Three or four sets (ADX_OVERLAP_DEPTH) take the wait off the cycle and gain
+            // 2 % -- but favouring the tail's waves (tail_first) gains 4.5 % with two sets and nothing more with four, so two it is.
             const size_t n_steps = steps.size();
             for (size_t k = 0; k < n_steps; ++k) {
-                const int par = (int)(k & 1);
+                const int par = (int)(k % (size_t)depth);
                 const int zi = (int)steps[k].z_index;
                 const float* z = nullptr;
                 if (zi >= 0 && steps[k].c3 != 0.f) {
                     if (1 + zi >= n_noise) { set_error("sample_a: schedule draws more noise tensors than were supplied"); return ADX_EINVAL; }
                     z = noise + (int64_t)(1 + zi) * n;
                 }
-                if (k >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
+                if (k >= (size_t)depth) ADX_HIP(hipStreamWaitEvent(s, ev_tail[par], 0));
                 ADX_HIP(enc_rows(rows_args(B, (int)k, par), cfg.precision, s, rows_mix()));
                 if (overlap_streams >= 3 && attn_g) {
                     // the row kernel of step k + 1 does not wait for this attention: its outputs (rows, queries, residual rows)
@@ -807,9 +824,8 @@ struct EngineA final : adx_engine {
                 ADX_HIP(hipEventRecord(ev_tail[par], side_stream));
                 float* tmp = xc; xc = xn; xn = tmp;
             }
-            // join: everything after the loop (un-normalise, the next chunk) is ordered behind the last two tails
-            ADX_HIP(hipStreamWaitEvent(s, ev_tail[(n_steps - 1) & 1], 0));
-            if (n_steps >= 2) ADX_HIP(hipStreamWaitEvent(s, ev_tail[(n_steps - 2) & 1], 0));
+            // join: everything after the loop (un-normalise, the next chunk) is ordered behind the last tails
+            for (size_t j = 1; j <= (size_t)depth && j <= n_steps; ++j) ADX_HIP(hipStreamWaitEvent(s, ev_tail[(n_steps - j) % (size_t)depth], 0));
         }
         for (size_t k = 0; !overlap && k < steps.size(); ++k) {
             if (!fused) ADX_TRY(set_time(B, temb_table + k * d, 0, s));   // the fused path reads the time token from tables

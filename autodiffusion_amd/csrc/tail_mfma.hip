@@ -330,6 +330,7 @@ __device__ __forceinline__ A8 attend16(const float* kv, const A8& qv, int row, i
 template <int MEM, int TRJ, int NW>
 __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW, NW == 1 ? 4 : 2) void tail_mfma_kernel(const TailMfmaArgs a) {
     constexpr int NT = NW == 1 ? 256 : 64 * NW;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) float vec[V_TOTAL];
     __shared__ __attribute__((aligned(16))) float kv_all[NW == 1 ? 4 : 1][(NW == 1 ? 16 : 16 * NW) * KV_LD];
     for (int i = threadIdx.x; i < V_TOTAL; i += NT) vec[i] = a.vecs[i];
