@@ -473,7 +473,7 @@ struct EngineA final : adx_engine {
     // kernels / the tail favoured: 256 scenarios 27.9 / 23.7, 512: 38.1 / 35.1, 1024: 52.6 / 50.3, 2048: 98.0 / 100.0 -- up to the batch
     // at which the row kernels alone fill the chip the tail's waves go first, above it the row kernels'.  Split-bf16 engine (its row
     // kernels are a third longer and leave the tail no slack): no priorities (1024 scenarios: 77.7, tail favoured 79.9, rows favoured 82.8).
-    bool tail_first(int B) const { return mix != 0 && B <= 1536; }
+    bool tail_first(int B) const { return mix != 0 && B <= 1280; }       // 1536 scenarios: 79.5 ms with the tail favoured, 76.5 with the row kernels
     int step_prio(int B) const { const char* e = getenv("ADX_A_PRIO"); return e ? atoi(e) : (mix && !tail_first(B) ? 3 : 0); }
     int tail_prio(int B) const { const char* e = getenv("ADX_TAIL_PRIO"); return e ? atoi(e) : (tail_first(B) ? 3 : 0); }
     bool half_io() const { return (mix & 8) && (mix & 0x31) == 0x31 && (mix & 6) == 6 && gate_table && attn_g; }
